@@ -1,0 +1,348 @@
+/* TEST INFRASTRUCTURE (see rtow_oracle.h).
+ *
+ * FP32 mirror: an independent CPU restatement of the arithmetic the HIP kernels perform for
+ * one path, written so that every rounding step is explicit.  GPU output must equal this
+ * bit for bit (hit ids, fixed-point sums, 8-bit pixels, segment counts).
+ *
+ * The arithmetic contract (the kernels follow the same one):
+ *   - every operation is a single IEEE-754 binary32 operation with round-to-nearest-even:
+ *     +, -, *, /, sqrtf, and fmaf exactly where written; nothing else may be fused
+ *     (compile with -ffp-contract=off);
+ *   - dot3(a,b) = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x));
+ *   - a ray direction is normalised once per segment, u = d * (1/sqrtf(dot3(d,d))), and the
+ *     reference's t_min = 0.001 (raytracer.nim:11), which is in units of |d|, becomes
+ *     0.001f*|d| in distance units;
+ *   - rayColor's recursion (raytracer.nim:5-20) becomes a loop that carries the product of
+ *     attenuations (throughput) outside-in;
+ *   - spheres with |radius| >= 100 (the 1000-unit ground sphere, raytracer.nim:79) are
+ *     intersected in binary64 from the binary32 ray, because |oc|^2 - r^2 cancels
+ *     catastrophically in binary32; all other spheres use binary32 only;
+ *   - a ray that starts on sphere j (it was scattered there) meets j again only at the
+ *     analytic far root t = -2 (oc.u): the near root is 0 by construction and is dropped, which
+ *     removes the binary32 self-intersections that t_min = 0.001|d| cannot catch when the
+ *     scattered direction is short;
+ *   - a uniform draw is (u32 >> 8) * 2^-24, so rand(-1.0..1.0) = 2*xi - 1 is exact;
+ *   - per-sample radiance is accumulated per channel as a 64-bit integer with 30 fractional
+ *     bits (order independent), and the writeColor step (raytracer.nim:22-28) runs in binary64
+ *     on that sum.
+ */
+#include "rtow_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float x, y, z; } f3;
+
+static inline float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+
+typedef struct {
+  float cx, cy, cz, r;  /* binary32 roundings of the scene description */
+  float r2;             /* r*r, or -inf for spheres taken by the binary64 path */
+  float inv_r;          /* 1/r */
+  int big;
+  int kind;
+  float ar, ag, ab;     /* albedo */
+  float fuzz, ir, inv_ir;
+} sph32;
+
+typedef struct {
+  f3 origin, llc, hor, ver, u, v;
+  float lens_radius;
+} cam32;
+
+#define BIG_RADIUS 100.0f
+#define FIX_ONE 1073741824.0f /* 2^30 */
+#define RADIANCE_CLAMP 3.5f
+
+static void prep_scene(const orc_sphere* in, int n, sph32* out) {
+  for (int j = 0; j < n; ++j) {
+    sph32 s;
+    s.cx = (float)in[j].center[0]; s.cy = (float)in[j].center[1]; s.cz = (float)in[j].center[2];
+    s.r = (float)in[j].radius;
+    s.big = fabsf(s.r) >= BIG_RADIUS;
+    s.r2 = s.big ? -INFINITY : s.r * s.r;
+    s.inv_r = 1.0f / s.r;
+    s.kind = in[j].kind;
+    s.ar = (float)in[j].albedo[0]; s.ag = (float)in[j].albedo[1]; s.ab = (float)in[j].albedo[2];
+    s.fuzz = (float)in[j].fuzz;
+    s.ir = (float)in[j].ir;
+    s.inv_ir = 1.0f / s.ir;
+    out[j] = s;
+  }
+}
+
+static f3 cvt3(const double* p) { f3 r = {(float)p[0], (float)p[1], (float)p[2]}; return r; }
+
+static void prep_camera(const orc_camera* c, cam32* o) {
+  o->origin = cvt3(c->origin); o->llc = cvt3(c->lower_left); o->hor = cvt3(c->horizontal);
+  o->ver = cvt3(c->vertical); o->u = cvt3(c->u); o->v = cvt3(c->v);
+  o->lens_radius = (float)c->lens_radius;
+}
+
+typedef struct { uint32_t key[2]; uint32_t k; } stream;
+static inline float draw(stream* g) {
+  return (float)(orc_draw_u32(g->key, g->k++) >> 8) * (1.0f / 16777216.0f);
+}
+static inline float draw_pm1(stream* g) { return fmaf(2.0f, draw(g), -1.0f); }
+
+/* rejection sample of the open unit ball (basetypes.nim:114-118), returns |p|^2 too */
+static inline f3 unit_ball(stream* g, float* l2_out) {
+  for (;;) {
+    f3 p;
+    p.x = draw_pm1(g); p.y = draw_pm1(g); p.z = draw_pm1(g);
+    const float l2 = dot3(p, p);
+    if (l2 >= 1.0f) continue;
+    *l2_out = l2;
+    return p;
+  }
+}
+
+/* closest hit over the whole list: candidate of a sphere is its near root if >= tmin, else its
+ * far root if >= tmin (hitrecord.nim:66-71); minimum wins, ties go to the later index
+ * (hittables.nim:84-88) */
+static int closest_hit(const sph32* w, int n, f3 o, f3 u, float tmin, int prev, float* t_out) {
+  float best = INFINITY;
+  int id = -1;
+  for (int j = 0; j < n; ++j) {
+    float t;
+    if (!w[j].big) {
+      const float ocx = o.x - w[j].cx, ocy = o.y - w[j].cy, ocz = o.z - w[j].cz;
+      float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
+      float m = fmaf(-ocx, ocx, w[j].r2); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
+      const float disc = fmaf(b, b, m);
+      if (!(disc >= 0.0f)) continue;
+      if (j == prev) {
+        t = -2.0f * b; /* origin lies on this sphere: roots are 0 and -2b */
+        if (t < tmin) continue;
+      } else {
+        const float s = sqrtf(disc);
+        t = -b - s;
+        if (t < tmin) {
+          t = -b + s;
+          if (t < tmin) continue;
+        }
+      }
+    } else {
+      const double ux = u.x, uy = u.y, uz = u.z;
+      const double ocx = (double)o.x - (double)w[j].cx, ocy = (double)o.y - (double)w[j].cy,
+                   ocz = (double)o.z - (double)w[j].cz;
+      const double a = ux * ux + uy * uy + uz * uz;
+      const double hb = ocx * ux + ocy * uy + ocz * uz;
+      const double c = ocx * ocx + ocy * ocy + ocz * ocz - (double)w[j].r * (double)w[j].r;
+      const double disc = hb * hb - a * c;
+      if (!(disc >= 0.0)) continue;
+      if (j == prev) {
+        t = (float)(-2.0 * hb / a);
+        if (t < tmin) continue;
+      } else {
+        const double sq = sqrt(disc);
+        t = (float)((-hb - sq) / a);
+        if (t < tmin) {
+          t = (float)((-hb + sq) / a);
+          if (t < tmin) continue;
+        }
+      }
+    }
+    if (t <= best) { best = t; id = j; }
+  }
+  *t_out = best;
+  return id;
+}
+
+typedef struct {
+  const sph32* w; int n; const cam32* cam;
+  int W, H, spp, max_depth; uint64_t seed;
+  const int32_t* rows; int n_rows; atomic_int* next_row;
+  uint8_t* rgb; uint64_t* accum; int32_t* hit_id; uint64_t segments;
+} job32;
+
+static inline uint64_t to_fix(float c) {
+  c = fminf(fmaxf(c, 0.0f), RADIANCE_CLAMP);
+  return (uint64_t)(uint32_t)(c * FIX_ONE);
+}
+
+/* one path: returns radiance in fixed point, counts world.hit queries */
+static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t sample, uint64_t fix[3],
+                       int* first_id, uint64_t* segments, int32_t* trail, int trail_cap, int* trail_len) {
+  const cam32* cam = jb->cam;
+  stream g;
+  orc_path_key(jb->seed, pixel, sample, g.key);
+  g.k = 0;
+  /* raytracer.nim:41-42 (u before v) */
+  const float xi1 = draw(&g), xi2 = draw(&g);
+  const float su = ((float)i + xi1) / (float)(jb->W - 1);
+  const float sv = ((float)j + xi2) / (float)(jb->H - 1);
+  /* camera.nim:34-39 with basetypes.nim:130-134 */
+  float lx, ly;
+  do { lx = draw_pm1(&g); ly = draw_pm1(&g); } while (fmaf(ly, ly, lx * lx) >= 1.0f);
+  const float rdx = cam->lens_radius * lx, rdy = cam->lens_radius * ly;
+  f3 off, o, d;
+  off.x = fmaf(cam->v.x, rdy, cam->u.x * rdx);
+  off.y = fmaf(cam->v.y, rdy, cam->u.y * rdx);
+  off.z = fmaf(cam->v.z, rdy, cam->u.z * rdx);
+  o.x = cam->origin.x + off.x; o.y = cam->origin.y + off.y; o.z = cam->origin.z + off.z;
+  d.x = fmaf(sv, cam->ver.x, fmaf(su, cam->hor.x, cam->llc.x)) - cam->origin.x - off.x;
+  d.y = fmaf(sv, cam->ver.y, fmaf(su, cam->hor.y, cam->llc.y)) - cam->origin.y - off.y;
+  d.z = fmaf(sv, cam->ver.z, fmaf(su, cam->hor.z, cam->llc.z)) - cam->origin.z - off.z;
+
+  float tr = 1.0f, tg = 1.0f, tb = 1.0f; /* throughput */
+  float rr = 0.0f, rg = 0.0f, rb = 0.0f; /* radiance of the path */
+  *first_id = -1;
+  int prev = -1; /* sphere the ray starts on */
+  for (int depth = jb->max_depth; depth > 0; --depth) { /* depth <= 0 -> black (raytracer.nim:8-9) */
+    ++*segments;
+    const float len = sqrtf(dot3(d, d));
+    const float il = 1.0f / len;
+    const f3 u = {d.x * il, d.y * il, d.z * il};
+    const float tmin = 0.001f * len;
+    float t;
+    const int id = closest_hit(jb->w, jb->n, o, u, tmin, prev, &t);
+    if (depth == jb->max_depth) *first_id = id;
+    if (trail) { if (*trail_len < trail_cap) trail[*trail_len] = id; ++*trail_len; }
+    if (id < 0) { /* sky, raytracer.nim:18-20 */
+      const float ts = 0.5f * (u.y + 1.0f);
+      const float a = 1.0f - ts;
+      rr = tr * fmaf(ts, 0.5f, a);
+      rg = tg * fmaf(ts, 0.7f, a);
+      rb = tb * fmaf(ts, 1.0f, a);
+      break;
+    }
+    const sph32* s = &jb->w[id];
+    f3 p = {fmaf(t, u.x, o.x), fmaf(t, u.y, o.y), fmaf(t, u.z, o.z)};
+    f3 n = {(p.x - s->cx) * s->inv_r, (p.y - s->cy) * s->inv_r, (p.z - s->cz) * s->inv_r};
+    const int front = dot3(u, n) < 0.0f;
+    if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
+    f3 nd; /* next direction */
+    if (s->kind == ORC_DIELECTRIC) { /* hitrecord.nim:107-125 */
+      const float ratio = front ? s->inv_ir : s->ir;
+      const float dn = dot3(u, n);
+      const float cos_t = fminf(-dn, 1.0f);
+      const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+      int reflect_it = ratio * sin_t > 1.0f;
+      if (!reflect_it) {
+        float r0 = (1.0f - ratio) / (1.0f + ratio);
+        r0 = r0 * r0;
+        const float x = 1.0f - cos_t;
+        const float x2 = x * x;
+        const float x5 = x2 * x2 * x;
+        const float refl = fmaf(1.0f - r0, x5, r0);
+        reflect_it = refl > draw(&g);
+      }
+      if (reflect_it) {
+        const float k2 = -2.0f * dn;
+        nd.x = fmaf(k2, n.x, u.x); nd.y = fmaf(k2, n.y, u.y); nd.z = fmaf(k2, n.z, u.z);
+      } else {
+        f3 perp = {ratio * fmaf(cos_t, n.x, u.x), ratio * fmaf(cos_t, n.y, u.y), ratio * fmaf(cos_t, n.z, u.z)};
+        const float par = -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+        nd.x = fmaf(par, n.x, perp.x); nd.y = fmaf(par, n.y, perp.y); nd.z = fmaf(par, n.z, perp.z);
+      }
+      /* attenuation is white */
+    } else {
+      float l2;
+      const f3 b = unit_ball(&g, &l2);
+      if (s->kind == ORC_LAMBERTIAN) { /* hitrecord.nim:82-92 */
+        const float ib = 1.0f / sqrtf(l2);
+        nd.x = fmaf(b.x, ib, n.x); nd.y = fmaf(b.y, ib, n.y); nd.z = fmaf(b.z, ib, n.z);
+        if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
+      } else { /* Metal, hitrecord.nim:94-99 */
+        const float k2 = -2.0f * dot3(u, n);
+        nd.x = fmaf(s->fuzz, b.x, fmaf(k2, n.x, u.x));
+        nd.y = fmaf(s->fuzz, b.y, fmaf(k2, n.y, u.y));
+        nd.z = fmaf(s->fuzz, b.z, fmaf(k2, n.z, u.z));
+        if (!(dot3(nd, n) > 0.0f)) break; /* absorbed: black */
+      }
+      tr *= s->ar; tg *= s->ag; tb *= s->ab;
+    }
+    o = p;
+    d = nd;
+    prev = id;
+  }
+  fix[0] = to_fix(rr); fix[1] = to_fix(rg); fix[2] = to_fix(rb);
+}
+
+static int quantise_fix(uint64_t sum, int spp) {
+  const double mean = (double)sum / ((double)spp * 1073741824.0);
+  double v = sqrt(mean);
+  v = v < 0.0 ? 0.0 : (v > 0.999 ? 0.999 : v);
+  return (int)(256.0 * v);
+}
+
+static void* render_rows32(void* arg) {
+  job32* jb = (job32*)arg;
+  uint64_t segments = 0;
+  for (;;) {
+    const int r = atomic_fetch_add(jb->next_row, 1);
+    if (r >= jb->n_rows) break;
+    const int y = jb->rows ? jb->rows[r] : r;
+    const int j = jb->H - 1 - y;
+    for (int i = 0; i < jb->W; ++i) {
+      uint64_t sum[3] = {0, 0, 0};
+      int first = -1;
+      for (int s = 0; s < jb->spp; ++s) {
+        uint64_t fix[3];
+        int id;
+        trace_path(jb, i, j, (uint32_t)(y * jb->W + i), (uint32_t)s, fix, &id, &segments, NULL, 0, NULL);
+        if (s == 0) first = id;
+        sum[0] += fix[0]; sum[1] += fix[1]; sum[2] += fix[2];
+      }
+      const size_t o = (size_t)r * jb->W + i;
+      if (jb->rgb)
+        for (int c = 0; c < 3; ++c) jb->rgb[3 * o + c] = (uint8_t)quantise_fix(sum[c], jb->spp);
+      if (jb->accum) { jb->accum[3 * o] = sum[0]; jb->accum[3 * o + 1] = sum[1]; jb->accum[3 * o + 2] = sum[2]; }
+      if (jb->hit_id) jb->hit_id[o] = first;
+    }
+  }
+  jb->segments = segments;
+  return NULL;
+}
+
+int orc_mirror32_render(const orc_sphere* spheres, int n_spheres, const orc_camera* cam, int W, int H,
+                        int spp, int max_depth, uint64_t seed, const int32_t* rows, int n_rows,
+                        int n_threads, uint8_t* rgb, uint64_t* accum_fix, int32_t* hit_id,
+                        uint64_t* ray_segments) {
+  if (W < 2 || H < 2 || spp < 1 || n_rows < 0 || n_spheres < 0) return -1;
+  sph32* w = (sph32*)malloc(sizeof(sph32) * (size_t)(n_spheres > 0 ? n_spheres : 1));
+  prep_scene(spheres, n_spheres, w);
+  cam32 c;
+  prep_camera(cam, &c);
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > n_rows) n_threads = n_rows > 0 ? n_rows : 1;
+  job32* jobs = (job32*)calloc((size_t)n_threads, sizeof(job32));
+  pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+  atomic_int next_row = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    job32 jb = {w, n_spheres, &c, W, H, spp, max_depth, seed, rows, n_rows, &next_row,
+                rgb, accum_fix, hit_id, 0};
+    jobs[t] = jb;
+  }
+  if (n_threads == 1) {
+    render_rows32(&jobs[0]);
+  } else {
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, render_rows32, &jobs[t]);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+  }
+  uint64_t total = 0;
+  for (int t = 0; t < n_threads; ++t) total += jobs[t].segments;
+  if (ray_segments) *ray_segments = total;
+  free(jobs); free(th); free(w);
+  return 0;
+}
+
+/* hit-index trail and fixed-point colour of one path (pixel column i, output row y, sample s) */
+int orc_mirror32_trace_path(const orc_sphere* spheres, int n_spheres, const orc_camera* cam, int W, int H,
+                            int max_depth, uint64_t seed, int i, int y, int sample, int32_t* trail,
+                            int trail_cap, uint64_t fix[3]) {
+  sph32* w = (sph32*)malloc(sizeof(sph32) * (size_t)(n_spheres > 0 ? n_spheres : 1));
+  prep_scene(spheres, n_spheres, w);
+  cam32 c;
+  prep_camera(cam, &c);
+  job32 jb = {w, n_spheres, &c, W, H, 1, max_depth, seed, NULL, 0, NULL, NULL, NULL, NULL, 0};
+  int first, len = 0;
+  uint64_t seg = 0, f[3];
+  trace_path(&jb, i, H - 1 - y, (uint32_t)(y * W + i), (uint32_t)sample, f, &first, &seg, trail, trail_cap, &len);
+  if (fix) { fix[0] = f[0]; fix[1] = f[1]; fix[2] = f[2]; }
+  free(w);
+  return len;
+}
