@@ -1,0 +1,122 @@
+/* rtow.h - C ABI of the MI355X (gfx950) renderer for the "Ray Tracing in One Weekend" hot path.
+ *
+ * The library replaces the body of the reference's
+ *     proc render*(img: Image, f: string, world: var HittablesList, camera: Camera,
+ *                  samplesPerPixel, maxDepth: int)                      (raytracer.nim:30-46)
+ * i.e. the j/i/s loops and everything they call: getRay (camera.nim:34-39), rayColor
+ * (raytracer.nim:5-20), HittablesList.hit (hittables.nim:79-88), Sphere.hit
+ * (hitrecord.nim:55-79), scatter (hitrecord.nim:82-132) and the colour maths of writeColor
+ * (raytracer.nim:22-28).  The host keeps the reference's types; it flattens them into the plain
+ * arrays below, makes one render call, and writes the PPM text itself.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns 0 on success or a negative rtow_status and
+ *     leaves a message for rtow_last_error() (thread local);
+ *   - the caller owns every host buffer; the library owns device state inside rtow_ctx;
+ *   - one rtow_ctx per host thread and per GPU; a context is not thread safe;
+ *   - all arithmetic on the device is binary32 except the intersection of spheres with
+ *     |radius| >= 100, which runs in binary64, and the final gamma/quantise step;
+ *   - randomness: draw k of path (pixel, sample) is a pure function of (seed, pixel, sample, k),
+ *     pixel = y*w + x with y = 0 the top image row.  It replaces the reference's single global
+ *     std/random stream (raytracer.nim:41-42,135; basetypes.nim:112,132; hitrecord.nim:119),
+ *     so an image does not depend on how it is split over GPUs.
+ */
+#ifndef RTOW_H
+#define RTOW_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtow_ctx rtow_ctx;
+
+typedef enum {
+  RTOW_OK = 0,
+  RTOW_ERR_INVALID = -1,  /* bad argument (the reference would hit an assert or a Nim exception) */
+  RTOW_ERR_DEVICE = -2,   /* a HIP call failed; message carries hipGetErrorString */
+  RTOW_ERR_STATE = -3,    /* render before set_scene/set_camera */
+  RTOW_ERR_NOMEM = -4
+} rtow_status;
+
+/* MaterialKind, hitrecord.nim:16-17 */
+enum { RTOW_LAMBERTIAN = 0, RTOW_METAL = 1, RTOW_DIELECTRIC = 2 };
+
+/* The eight private fields of Camera (camera.nim:4-10), rounded to binary32 by the host after
+ * initCamera (camera.nim:12-31) has computed them in binary64. */
+typedef struct {
+  float origin[3];
+  float lower_left[3];
+  float horizontal[3];
+  float vertical[3];
+  float u[3], v[3], w[3];
+  float lens_radius;
+} rtow_camera;
+
+/* statistics of the most recent render on a context */
+typedef struct {
+  uint64_t ray_segments;  /* world.hit queries (raytracer.nim:11): the numerator of Mrays/s */
+  uint64_t paths;         /* pixels x samples */
+  float trace_ms;         /* device time of the path-tracing kernel (HIP events) */
+  float total_ms;         /* device time of clear + trace + resolve (HIP events) */
+  int32_t n_spheres;
+  int32_t n_big;          /* spheres routed through the binary64 test */
+} rtow_stats;
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* rtow_last_error(void);
+
+/* Library version: major*10000 + minor*100 + patch. */
+int rtow_version(void);
+
+/* Number of visible HIP devices. */
+int rtow_device_count(int* count);
+
+/* Create / destroy a context bound to one device.  Replaces nothing in the reference (it has
+ * no device); it is where the HIP stream and the workspace live. */
+int rtow_create(int device, rtow_ctx** ctx);
+int rtow_destroy(rtow_ctx* ctx);
+
+/* Upload a HittablesList (hittables.nim:10-13) flattened to structure-of-arrays, in list order:
+ * index i here is insertion index i there, which decides ties (hittables.nim:84-88).
+ * center_* / radius: Sphere.center, Sphere.radius (hitrecord.nim:11-14; a negative radius is
+ * legal and flips the normal, raytracer.nim:72).  kind: RTOW_* per sphere.  albedo_rgb: 3 floats
+ * per sphere (ignored for dielectrics).  fuzz: Metal.fuzz.  ir: Dielectric.ir.
+ * All pointers are host pointers; the data is copied.  n may be 0 (every ray sees the sky). */
+int rtow_set_scene(rtow_ctx* ctx, int n, const float* center_x, const float* center_y,
+                   const float* center_z, const float* radius, const uint8_t* kind,
+                   const float* albedo_rgb, const float* fuzz, const float* ir);
+
+/* Upload the camera (camera.nim:4-10). */
+int rtow_set_camera(rtow_ctx* ctx, const rtow_camera* cam);
+
+/* render (raytracer.nim:30-46) for the image rows listed in rows[0..n_rows): row 0 is the top
+ * row, the first one the reference writes.  rows == NULL means rows 0..h-1 (then n_rows must be
+ * h).  Outputs are n_rows x w in rows[] order, host pointers, any may be NULL:
+ *   rgb_out      3 bytes per pixel: the three integers writeColor prints (raytracer.nim:28)
+ *   accum_out    3 uint64 per pixel: per-channel radiance sums, fixed point, 30 fractional bits
+ *   hit_id_out   list index hit by the primary ray of sample 0, -1 for the sky (debug plane)
+ * Blocks until the image is in host memory.  w,h >= 2; spp,max_depth >= 1. */
+int rtow_render(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uint64_t seed,
+                const int32_t* rows, int n_rows, uint8_t* rgb_out, uint64_t* accum_out,
+                int32_t* hit_id_out);
+
+/* Same work, but asynchronous and device resident: rgb_dev is a DEVICE pointer to n_rows*w*3
+ * bytes (may be NULL: the image then stays in the context's workspace).  Work is enqueued on
+ * the context's stream; rtow_sync() waits for it.  Used when the caller gathers tiles from
+ * several GPUs itself, and by the benchmark (nothing crosses PCIe in the timed region). */
+int rtow_render_async(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uint64_t seed,
+                      const int32_t* rows, int n_rows, void* rgb_dev);
+int rtow_sync(rtow_ctx* ctx);
+
+/* Statistics of the last completed render (call after rtow_render or rtow_sync). */
+int rtow_get_stats(rtow_ctx* ctx, rtow_stats* out);
+
+/* The context's HIP stream (hipStream_t) as an opaque pointer, for callers that order their own
+ * device work after a render. */
+int rtow_get_stream(rtow_ctx* ctx, void** stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTOW_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of librtow_hip.so (the C ABI of include/rtow.h).
+
+Loading fails loudly when the library has not been built: nothing in this package can render
+without it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librtow_hip.so")
+
+LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
+
+
+class RtowError(RuntimeError):
+    """A call into librtow_hip.so returned a negative status."""
+
+    def __init__(self, status, message):
+        super().__init__(f"rtow status {status}: {message}")
+        self.status = status
+
+
+class CameraStruct(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left", C.c_float * 3),
+                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("lens_radius", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ray_segments", C.c_uint64), ("paths", C.c_uint64), ("trace_ms", C.c_float),
+                ("total_ms", C.c_float), ("n_spheres", C.c_int32), ("n_big", C.c_int32)]
+
+
+# every symbol include/rtow.h declares
+SYMBOLS = ["rtow_last_error", "rtow_version", "rtow_device_count", "rtow_create", "rtow_destroy",
+           "rtow_set_scene", "rtow_set_camera", "rtow_render", "rtow_render_async", "rtow_sync",
+           "rtow_get_stats", "rtow_get_stream"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C raytracinginoneweekend_amd/csrc` "
+            "(or __graft_entry__.build()); this package has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rtow_last_error.restype = C.c_char_p
+    L.rtow_last_error.argtypes = []
+    L.rtow_version.argtypes = []
+    L.rtow_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.rtow_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.rtow_destroy.argtypes = [vp]
+    L.rtow_set_scene.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rtow_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    L.rtow_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp, vp, vp]
+    L.rtow_render_async.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp]
+    L.rtow_sync.argtypes = [vp]
+    L.rtow_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rtow_get_stream.argtypes = [vp, C.POINTER(vp)]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise RtowError(status, lib().rtow_last_error().decode("utf-8", "replace"))

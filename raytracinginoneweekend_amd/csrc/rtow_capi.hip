@@ -1,0 +1,299 @@
+// C ABI of the renderer (declared in include/rtow.h): context, scene/camera upload, render.
+// No CPU rendering path exists here: every entry point that produces pixels launches the HIP
+// kernels and fails with RTOW_ERR_DEVICE if it cannot.
+#include "../../include/rtow.h"
+#include "rtow_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(RTOW_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+// a device buffer that only grows
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct rtow_ctx {
+  int device = 0;
+  int n_cu = 0;
+  int blocks_per_cu = 1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, after clear, after trace, end
+
+  // scene
+  bool have_scene = false, have_camera = false;
+  int n_spheres = 0, n_geom_pad = 0, n_big = 0;
+  DevBuf geom, big, shade;
+  rtow::CameraParams cam;
+
+  // per-render workspace
+  DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..11] chunk counter
+  uint64_t* host_counters = nullptr;          // pinned, 16 bytes
+
+  // last render
+  bool pending = false;
+  int last_w = 0, last_h = 0, last_spp = 0, last_rows = 0;
+  rtow_stats stats = {};
+};
+
+extern "C" {
+
+const char* rtow_last_error(void) { return g_err.c_str(); }
+
+int rtow_version(void) { return 100; }
+
+int rtow_device_count(int* count) {
+  if (!count) return fail(RTOW_ERR_INVALID, "rtow_device_count: count is NULL");
+  HIP_TRY(hipGetDeviceCount(count));
+  return RTOW_OK;
+}
+
+int rtow_create(int device, rtow_ctx** out) {
+  if (!out) return fail(RTOW_ERR_INVALID, "rtow_create: ctx is NULL");
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(RTOW_ERR_INVALID, "rtow_create: device %d of %d", device, n);
+  HIP_TRY(hipSetDevice(device));
+  rtow_ctx* c = new (std::nothrow) rtow_ctx;
+  if (!c) return fail(RTOW_ERR_NOMEM, "rtow_create: out of host memory");
+  c->device = device;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->host_counters, 16, hipHostMallocDefault);
+  if (e == hipSuccess) e = c->counters.reserve(16);
+  if (e != hipSuccess) {
+    rtow_destroy(c);
+    return fail(RTOW_ERR_DEVICE, "rtow_create: %s", hipGetErrorString(e));
+  }
+  c->n_cu = prop.multiProcessorCount;
+  c->blocks_per_cu = rtow::trace_blocks_per_cu();
+  *out = c;
+  return RTOW_OK;
+}
+
+int rtow_destroy(rtow_ctx* c) {
+  if (!c) return RTOW_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->geom.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
+  c->hit_id.release(); c->rgb.release(); c->counters.release();
+  if (c->host_counters) (void)hipHostFree(c->host_counters);
+  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return RTOW_OK;
+}
+
+int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
+                   const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
+                   const float* ir) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_set_scene: ctx is NULL");
+  if (n < 0) return fail(RTOW_ERR_INVALID, "rtow_set_scene: n = %d", n);
+  if (n > 0 && (!cx || !cy || !cz || !radius || !kind || !albedo || !fuzz || !ir))
+    return fail(RTOW_ERR_INVALID, "rtow_set_scene: NULL array with n = %d", n);
+  for (int j = 0; j < n; ++j) {
+    if (kind[j] > RTOW_DIELECTRIC) return fail(RTOW_ERR_INVALID, "rtow_set_scene: kind[%d] = %d", j, (int)kind[j]);
+    if (!(std::fabs(radius[j]) > 0.0f) || !std::isfinite(radius[j]))
+      return fail(RTOW_ERR_INVALID, "rtow_set_scene: radius[%d] = %g", j, (double)radius[j]);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // a render may still be reading the old tables
+
+  const int n_pad = ((n + rtow::kGeomPad - 1) / rtow::kGeomPad) * rtow::kGeomPad;
+  std::vector<float4> geom((size_t)(n_pad > 0 ? n_pad : 1));
+  std::vector<rtow::SphereShade> shade((size_t)(n > 0 ? n : 1));
+  std::vector<rtow::BigSphere> big;
+  for (int j = 0; j < n_pad; ++j) geom[j] = make_float4(0.f, 0.f, 0.f, -INFINITY);
+  for (int j = 0; j < n; ++j) {
+    const float r = radius[j];
+    const bool is_big = std::fabs(r) >= rtow::kBigRadius;
+    geom[j] = make_float4(cx[j], cy[j], cz[j], is_big ? -INFINITY : r * r);
+    if (is_big) {
+      rtow::BigSphere b;
+      b.cx = cx[j]; b.cy = cy[j]; b.cz = cz[j]; b.r = r; b.index = j; b.pad_ = 0;
+      big.push_back(b);
+    }
+    rtow::SphereShade& s = shade[j];
+    s.cx = cx[j]; s.cy = cy[j]; s.cz = cz[j]; s.inv_r = 1.0f / r;
+    s.ar = albedo[3 * j]; s.ag = albedo[3 * j + 1]; s.ab = albedo[3 * j + 2]; s.fuzz = fuzz[j];
+    s.kind = kind[j]; s.ir = ir[j]; s.inv_ir = 1.0f / ir[j]; s.pad_ = 0.f;
+  }
+  HIP_TRY(c->geom.reserve(sizeof(float4) * geom.size()));
+  HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
+  HIP_TRY(c->big.reserve(sizeof(rtow::BigSphere) * (big.empty() ? 1 : big.size())));
+  HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float4) * geom.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice));
+  if (!big.empty())
+    HIP_TRY(hipMemcpy(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice));
+  c->n_spheres = n; c->n_geom_pad = n_pad; c->n_big = (int)big.size();
+  c->have_scene = true;
+  return RTOW_OK;
+}
+
+int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
+  if (!c || !cam) return fail(RTOW_ERR_INVALID, "rtow_set_camera: NULL argument");
+  auto v3 = [](const float* p) { rtow::f3 r = {p[0], p[1], p[2]}; return r; };
+  c->cam.origin = v3(cam->origin); c->cam.llc = v3(cam->lower_left); c->cam.hor = v3(cam->horizontal);
+  c->cam.ver = v3(cam->vertical); c->cam.u = v3(cam->u); c->cam.v = v3(cam->v);
+  c->cam.lens_radius = cam->lens_radius;
+  c->have_camera = true;
+  return RTOW_OK;
+}
+
+static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed,
+                          const int32_t* rows, int n_rows, void* rgb_dev, bool want_hit_id) {
+  if (!c) return fail(RTOW_ERR_INVALID, "render: ctx is NULL");
+  if (!c->have_scene || !c->have_camera)
+    return fail(RTOW_ERR_STATE, "render: call rtow_set_scene and rtow_set_camera first");
+  if (w < 2 || h < 2) return fail(RTOW_ERR_INVALID, "render: image %dx%d (width and height must be >= 2)", w, h);
+  if (spp < 1 || max_depth < 1) return fail(RTOW_ERR_INVALID, "render: spp = %d, max_depth = %d", spp, max_depth);
+  if (n_rows < 0 || n_rows > h) return fail(RTOW_ERR_INVALID, "render: n_rows = %d of %d", n_rows, h);
+  if (!rows && n_rows != h) return fail(RTOW_ERR_INVALID, "render: rows == NULL needs n_rows == h");
+  if (rows)
+    for (int r = 0; r < n_rows; ++r)
+      if (rows[r] < 0 || rows[r] >= h) return fail(RTOW_ERR_INVALID, "render: rows[%d] = %d of %d", r, rows[r], h);
+  const uint64_t n_pixels = (uint64_t)n_rows * (uint64_t)w;
+  if (n_pixels >= 0x7fffffffull / 3) return fail(RTOW_ERR_INVALID, "render: %llu pixels in one call", (unsigned long long)n_pixels);
+
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->pending) HIP_TRY(hipStreamSynchronize(c->stream));
+
+  // work chunks: runs of chunk_paths consecutive paths in pixel-major order
+  const uint32_t chunk_paths = 512;
+  const uint64_t total_paths = n_pixels * (uint64_t)spp;
+  const uint64_t n_chunks64 = (total_paths + chunk_paths - 1) / chunk_paths;
+  if (n_chunks64 >= 0xffff0000ull) return fail(RTOW_ERR_INVALID, "render: too many work chunks");
+
+  HIP_TRY(c->accum.reserve(sizeof(unsigned long long) * 3 * (n_pixels ? n_pixels : 1)));
+  HIP_TRY(c->rgb.reserve(3 * (n_pixels ? n_pixels : 1)));
+  if (want_hit_id) HIP_TRY(c->hit_id.reserve(sizeof(int32_t) * (n_pixels ? n_pixels : 1)));
+  if (rows) {
+    HIP_TRY(c->rows.reserve(sizeof(int32_t) * (size_t)(n_rows ? n_rows : 1)));
+    HIP_TRY(hipMemcpyAsync(c->rows.p, rows, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
+  }
+
+  rtow::TraceParams p;
+  p.cam = c->cam;
+  p.geom = (const float4*)c->geom.p; p.n_geom_pad = c->n_geom_pad;
+  p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
+  p.shade = (const rtow::SphereShade*)c->shade.p;
+  p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth;
+  p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+  p.rows = rows ? (const int32_t*)c->rows.p : nullptr; p.n_rows = n_rows;
+  p.n_chunks = (uint32_t)n_chunks64; p.chunk_paths = chunk_paths; p.total_paths = total_paths;
+  p.seg_counter = (unsigned long long*)c->counters.p;
+  p.chunk_counter = (unsigned int*)((char*)c->counters.p + 8);
+  p.accum = (unsigned long long*)c->accum.p;
+  p.hit_id = want_hit_id ? (int32_t*)c->hit_id.p : nullptr;
+
+  uint8_t* rgb = rgb_dev ? (uint8_t*)rgb_dev : (uint8_t*)c->rgb.p;
+  const uint64_t waves_needed = (total_paths + 63) / 64;
+  int grid = c->n_cu * c->blocks_per_cu;
+  const uint64_t blocks_needed = (waves_needed + (rtow::kTraceThreads / 64) - 1) / (rtow::kTraceThreads / 64);
+  if ((uint64_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
+
+  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(hipMemsetAsync(c->counters.p, 0, 16, c->stream));
+  HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
+  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+  if (n_pixels) rtow::launch_trace(p, grid, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+  rtow::launch_resolve((const unsigned long long*)c->accum.p, rgb, (uint32_t)(3 * n_pixels), spp, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+  HIP_TRY(hipMemcpyAsync(c->host_counters, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+  c->pending = true;
+  c->last_w = w; c->last_h = h; c->last_spp = spp; c->last_rows = n_rows;
+  return RTOW_OK;
+}
+
+int rtow_sync(rtow_ctx* c) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_sync: ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->pending) {
+    c->pending = false;
+    c->stats.ray_segments = c->host_counters[0];
+    c->stats.paths = (uint64_t)c->last_rows * (uint64_t)c->last_w * (uint64_t)c->last_spp;
+    c->stats.n_spheres = c->n_spheres;
+    c->stats.n_big = c->n_big;
+    HIP_TRY(hipEventElapsedTime(&c->stats.trace_ms, c->ev[1], c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&c->stats.total_ms, c->ev[0], c->ev[3]));
+  }
+  return RTOW_OK;
+}
+
+int rtow_render_async(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed,
+                      const int32_t* rows, int n_rows, void* rgb_dev) {
+  return enqueue_render(c, w, h, spp, max_depth, seed, rows, n_rows, rgb_dev, false);
+}
+
+int rtow_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed, const int32_t* rows,
+                int n_rows, uint8_t* rgb_out, uint64_t* accum_out, int32_t* hit_id_out) {
+  int rc = enqueue_render(c, w, h, spp, max_depth, seed, rows, n_rows, nullptr, hit_id_out != nullptr);
+  if (rc != RTOW_OK) return rc;
+  rc = rtow_sync(c);
+  if (rc != RTOW_OK) return rc;
+  const size_t n_pixels = (size_t)n_rows * (size_t)w;
+  if (rgb_out && n_pixels) HIP_TRY(hipMemcpy(rgb_out, c->rgb.p, 3 * n_pixels, hipMemcpyDeviceToHost));
+  if (accum_out && n_pixels)
+    HIP_TRY(hipMemcpy(accum_out, c->accum.p, sizeof(uint64_t) * 3 * n_pixels, hipMemcpyDeviceToHost));
+  if (hit_id_out && n_pixels)
+    HIP_TRY(hipMemcpy(hit_id_out, c->hit_id.p, sizeof(int32_t) * n_pixels, hipMemcpyDeviceToHost));
+  return RTOW_OK;
+}
+
+int rtow_get_stats(rtow_ctx* c, rtow_stats* out) {
+  if (!c || !out) return fail(RTOW_ERR_INVALID, "rtow_get_stats: NULL argument");
+  *out = c->stats;
+  return RTOW_OK;
+}
+
+int rtow_get_stream(rtow_ctx* c, void** stream) {
+  if (!c || !stream) return fail(RTOW_ERR_INVALID, "rtow_get_stream: NULL argument");
+  *stream = (void*)c->stream;
+  return RTOW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// Launch interface between the C ABI layer and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rtow_path.h"
+
+namespace rtow {
+
+constexpr int kTraceThreads = 256;   // 4 wavefronts per workgroup
+constexpr int kGeomPad = 8;          // the regular sphere table is padded to a multiple of this
+
+struct TraceParams {
+  CameraParams cam;
+  const float4* geom;        // n_geom_pad records (cx, cy, cz, r^2 | -inf), list order
+  int n_geom_pad;
+  const BigSphere* big;      // spheres intersected in binary64
+  int n_big;
+  const SphereShade* shade;  // one record per list entry
+  int W, H, spp, max_depth;
+  uint32_t seed_lo, seed_hi;
+  const int32_t* rows;       // image rows to render (0 = top), or nullptr for 0..n_rows-1
+  int n_rows;
+  uint32_t n_chunks, chunk_paths;   // work is handed out in runs of chunk_paths consecutive paths
+  unsigned long long total_paths;   // n_rows * W * spp
+  unsigned int* chunk_counter;      // zeroed before launch
+  unsigned long long* accum;        // n_rows*W*3 fixed-point sums, zeroed before launch
+  int32_t* hit_id;                  // n_rows*W or nullptr
+  unsigned long long* seg_counter;  // zeroed before launch
+};
+
+void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream);
+void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
+                    hipStream_t stream);
+int trace_blocks_per_cu();
+
+}  // namespace rtow

@@ -1,0 +1,255 @@
+// Per-path arithmetic of the renderer: random streams, camera rays, candidate roots, material
+// scattering, radiance accumulation.  Everything here is a pure function of its arguments and is
+// written so that each rounding step is explicit (one IEEE binary32 operation per operator,
+// fused only where fmaf is spelled out).  The translation units that include this header are
+// compiled with -ffp-contract=off; the kernels add the wave-level scheduling and the sphere scan
+// around these functions.
+//
+// Reference being accelerated (Nim, FP64): raytracer.nim:5-46, camera.nim:34-39,
+// hitrecord.nim:51-132, hittables.nim:79-88, basetypes.nim:87-134.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RTOW_HD __host__ __device__ __forceinline__
+#else
+#define RTOW_HD inline
+#endif
+
+namespace rtow {
+
+constexpr float kBigRadius = 100.0f;        // |r| >= this: intersect in binary64
+constexpr float kFixOne = 1073741824.0f;    // 2^30: fixed-point scale of radiance sums
+constexpr double kFixOneD = 1073741824.0;
+constexpr float kRadianceClamp = 3.5f;      // keeps one sample's channel inside 32 bits
+constexpr float kTMin = 0.001f;             // raytracer.nim:11, in units of |dir|
+constexpr uint32_t kGolden = 0x9E3779B9u;
+
+enum : int { kLambertian = 0, kMetal = 1, kDielectric = 2 };
+
+struct f3 { float x, y, z; };
+
+RTOW_HD float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+
+// ------------------------------------------------------------------ random stream of a path
+// Draw k of path (pixel, sample) is hash(key0 + k*golden) with key1 folded in half way:
+// a pure function of (seed, pixel, sample, k).  It stands in for the reference's global
+// std/random stream (raytracer.nim:41-42, basetypes.nim:112,132, hitrecord.nim:119).
+RTOW_HD uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+struct Stream {
+  uint32_t x0;    // key0 + k*golden for the next draw
+  uint32_t key1;
+};
+
+RTOW_HD Stream stream_begin(uint32_t seed_lo, uint32_t seed_hi, uint32_t pixel, uint32_t sample) {
+  Stream g;
+  g.x0 = mix32(mix32(pixel ^ seed_lo) + sample);
+  g.key1 = mix32(mix32(sample ^ seed_hi ^ 0xA511E9B3U) + pixel);
+  return g;
+}
+
+RTOW_HD uint32_t draw_u32(Stream& g) {
+  uint32_t x = g.x0;
+  g.x0 += kGolden;
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x ^= g.key1; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+// uniform in [0,1), 24 random bits: rand(1.0)
+RTOW_HD float draw(Stream& g) { return (float)(draw_u32(g) >> 8) * (1.0f / 16777216.0f); }
+// rand(-1.0 .. 1.0) = rand(2.0) - 1.0; exact in binary32
+RTOW_HD float draw_pm1(Stream& g) { return fmaf(2.0f, draw(g), -1.0f); }
+
+// randomInUnitSphere (basetypes.nim:114-118): x, y, z drawn in order, rejected while |p|^2 >= 1
+RTOW_HD f3 unit_ball(Stream& g, float& l2) {
+  f3 p;
+  do {
+    p.x = draw_pm1(g); p.y = draw_pm1(g); p.z = draw_pm1(g);
+    l2 = dot3(p, p);
+  } while (l2 >= 1.0f);
+  return p;
+}
+
+// ------------------------------------------------------------------ camera (camera.nim:4-10,34-39)
+struct CameraParams {
+  f3 origin, llc, hor, ver, u, v;
+  float lens_radius;
+};
+
+// Pixel jitter (raytracer.nim:41-42, u drawn before v) and thin-lens ray (camera.nim:34-39 with
+// randomInUnitDisk, basetypes.nim:130-134).  i = column, j = row counted from the bottom.
+RTOW_HD void camera_ray(const CameraParams& cam, int i, int j, int W, int H, Stream& g, f3& o, f3& d) {
+  const float xi1 = draw(g), xi2 = draw(g);
+  const float su = ((float)i + xi1) / (float)(W - 1);
+  const float sv = ((float)j + xi2) / (float)(H - 1);
+  float lx, ly;
+  do { lx = draw_pm1(g); ly = draw_pm1(g); } while (fmaf(ly, ly, lx * lx) >= 1.0f);
+  const float rdx = cam.lens_radius * lx, rdy = cam.lens_radius * ly;
+  f3 off;
+  off.x = fmaf(cam.v.x, rdy, cam.u.x * rdx);
+  off.y = fmaf(cam.v.y, rdy, cam.u.y * rdx);
+  off.z = fmaf(cam.v.z, rdy, cam.u.z * rdx);
+  o.x = cam.origin.x + off.x; o.y = cam.origin.y + off.y; o.z = cam.origin.z + off.z;
+  d.x = fmaf(sv, cam.ver.x, fmaf(su, cam.hor.x, cam.llc.x)) - cam.origin.x - off.x;
+  d.y = fmaf(sv, cam.ver.y, fmaf(su, cam.hor.y, cam.llc.y)) - cam.origin.y - off.y;
+  d.z = fmaf(sv, cam.ver.z, fmaf(su, cam.hor.z, cam.llc.z)) - cam.origin.z - off.z;
+}
+
+// Unit direction and the reference's t_min expressed as a distance.
+RTOW_HD void segment_begin(f3 d, f3& u, float& tmin) {
+  const float len = sqrtf(dot3(d, d));
+  const float il = 1.0f / len;
+  u.x = d.x * il; u.y = d.y * il; u.z = d.z * il;
+  tmin = kTMin * len;
+}
+
+// ------------------------------------------------------------------ candidate roots
+// Sphere.hit (hitrecord.nim:55-79) with |dir| = 1: b = oc.u, disc = b^2 - (|oc|^2 - r^2) >= 0 on
+// entry.  A sphere offers its near root if it is >= tmin, otherwise its far root if that is
+// >= tmin (hitrecord.nim:66-71).  self: the ray starts on this sphere, so the near root is 0 by
+// construction and only t = -2b is offered.
+RTOW_HD bool regular_candidate(float b, float disc, float tmin, bool self, float& t) {
+  if (self) {
+    t = -2.0f * b;
+    return !(t < tmin);
+  }
+  const float s = sqrtf(disc);
+  t = -b - s;
+  if (t < tmin) {
+    t = -b + s;
+    if (t < tmin) return false;
+  }
+  return true;
+}
+
+struct BigSphere {
+  double cx, cy, cz, r;
+  int32_t index;  // position in the list
+  int32_t pad_;
+};
+
+// The same test in binary64 for |r| >= kBigRadius, from the binary32 ray.
+RTOW_HD bool big_candidate(f3 o, f3 u, const BigSphere& s, float tmin, bool self, float& t) {
+  const double ux = u.x, uy = u.y, uz = u.z;
+  const double ocx = (double)o.x - s.cx, ocy = (double)o.y - s.cy, ocz = (double)o.z - s.cz;
+  const double a = ux * ux + uy * uy + uz * uz;
+  const double hb = ocx * ux + ocy * uy + ocz * uz;
+  const double c = ocx * ocx + ocy * ocy + ocz * ocz - s.r * s.r;
+  const double disc = hb * hb - a * c;
+  if (!(disc >= 0.0)) return false;
+  if (self) {
+    t = (float)(-2.0 * hb / a);
+    return !(t < tmin);
+  }
+  const double sq = sqrt(disc);
+  t = (float)((-hb - sq) / a);
+  if (t < tmin) {
+    t = (float)((-hb + sq) / a);
+    if (t < tmin) return false;
+  }
+  return true;
+}
+
+// closest-so-far update: smaller t wins, equal t goes to the later list index
+// (hittables.nim:84-88 accepts root <= closestSoFar while scanning in list order)
+RTOW_HD void offer(float t, int j, float& best, int& id) {
+  if (t < best || (t == best && j > id)) { best = t; id = j; }
+}
+
+// ------------------------------------------------------------------ shading
+struct SphereShade {   // 48 bytes, fetched by hit index only
+  float cx, cy, cz, inv_r;
+  float ar, ag, ab, fuzz;
+  int32_t kind; float ir, inv_ir, pad_;
+};
+
+// sky gradient (raytracer.nim:18-20) times throughput
+RTOW_HD void shade_sky(f3 u, float tr, float tg, float tb, float& rr, float& rg, float& rb) {
+  const float ts = 0.5f * (u.y + 1.0f);
+  const float a = 1.0f - ts;
+  rr = tr * fmaf(ts, 0.5f, a);
+  rg = tg * fmaf(ts, 0.7f, a);
+  rb = tb * fmaf(ts, 1.0f, a);
+}
+
+// Hit record (hitrecord.nim:73-77) + scatter (hitrecord.nim:82-132) at distance t along unit u.
+// Updates origin, direction and throughput; returns false when the path is absorbed (Metal
+// scattering below the surface, hitrecord.nim:99), in which case it contributes black.
+RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3& d_next,
+                       float& tr, float& tg, float& tb) {
+  const f3 p = {fmaf(t, u.x, o.x), fmaf(t, u.y, o.y), fmaf(t, u.z, o.z)};
+  f3 n = {(p.x - s.cx) * s.inv_r, (p.y - s.cy) * s.inv_r, (p.z - s.cz) * s.inv_r};
+  const bool front = dot3(u, n) < 0.0f;  // setFaceNormal, hitrecord.nim:51-53
+  if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
+  f3 nd;
+  if (s.kind == kDielectric) {  // hitrecord.nim:107-125
+    const float ratio = front ? s.inv_ir : s.ir;
+    const float dn = dot3(u, n);
+    const float cos_t = fminf(-dn, 1.0f);
+    const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+    bool reflect_it = ratio * sin_t > 1.0f;
+    if (!reflect_it) {  // the draw happens only when refraction is possible
+      float r0 = (1.0f - ratio) / (1.0f + ratio);
+      r0 = r0 * r0;
+      const float x = 1.0f - cos_t;
+      const float x2 = x * x;
+      const float x5 = x2 * x2 * x;
+      const float refl = fmaf(1.0f - r0, x5, r0);  // Schlick, hitrecord.nim:101-105
+      reflect_it = refl > draw(g);
+    }
+    if (reflect_it) {  // reflect, basetypes.nim:101-102
+      const float k2 = -2.0f * dn;
+      nd.x = fmaf(k2, n.x, u.x); nd.y = fmaf(k2, n.y, u.y); nd.z = fmaf(k2, n.z, u.z);
+    } else {           // refract, basetypes.nim:104-108
+      const f3 perp = {ratio * fmaf(cos_t, n.x, u.x), ratio * fmaf(cos_t, n.y, u.y),
+                       ratio * fmaf(cos_t, n.z, u.z)};
+      const float par = -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+      nd.x = fmaf(par, n.x, perp.x); nd.y = fmaf(par, n.y, perp.y); nd.z = fmaf(par, n.z, perp.z);
+    }
+  } else {
+    float l2;
+    const f3 b = unit_ball(g, l2);
+    if (s.kind == kLambertian) {  // hitrecord.nim:82-92
+      const float ib = 1.0f / sqrtf(l2);
+      nd.x = fmaf(b.x, ib, n.x); nd.y = fmaf(b.y, ib, n.y); nd.z = fmaf(b.z, ib, n.z);
+      if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;  // nearZero
+    } else {                      // Metal, hitrecord.nim:94-99
+      const float k2 = -2.0f * dot3(u, n);
+      nd.x = fmaf(s.fuzz, b.x, fmaf(k2, n.x, u.x));
+      nd.y = fmaf(s.fuzz, b.y, fmaf(k2, n.y, u.y));
+      nd.z = fmaf(s.fuzz, b.z, fmaf(k2, n.z, u.z));
+      if (!(dot3(nd, n) > 0.0f)) return false;
+    }
+    tr *= s.ar; tg *= s.ag; tb *= s.ab;
+  }
+  o = p;
+  d_next = nd;
+  return true;
+}
+
+// one sample's channel radiance -> fixed point (30 fractional bits)
+RTOW_HD uint32_t to_fix(float c) {
+  c = fminf(fmaxf(c, 0.0f), kRadianceClamp);
+  return (uint32_t)(c * kFixOne);
+}
+
+// writeColor (raytracer.nim:22-28) on a fixed-point channel sum: mean, sqrt gamma,
+// clamp(0, 0.999), 256x, truncate.  Runs in binary64.
+RTOW_HD int quantise_fix(uint64_t sum, int spp) {
+  const double mean = (double)sum / ((double)spp * kFixOneD);
+  double v = sqrt(mean);
+  v = v < 0.0 ? 0.0 : (v > 0.999 ? 0.999 : v);
+  return (int)(256.0 * v);
+}
+
+}  // namespace rtow

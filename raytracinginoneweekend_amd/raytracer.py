@@ -1,0 +1,233 @@
+"""Driver with the reference's interface (raytracer.nim): render, writeColor, the three scene
+builders and main.  `render` keeps the reference's signature; its triple loop
+(raytracer.nim:36-45) is one call into librtow_hip.so.
+"""
+import ctypes as C
+import math
+import sys
+
+import numpy as np
+
+from . import _lib, nimrandom
+from .basetypes import Color, Image, Point, color, length, point, randomVec, vec3
+from .camera import Camera, initCamera
+from .hitrecord import (Sphere, initDielectric, initLambertian, initMaterial, initMetal)
+from .hittables import HittablesList, initHittables
+
+RENDER_SEED = 0xE7  # raytracer.nim:135
+
+
+class Renderer:
+    """One rtow_ctx: a GPU, its stream and its workspace.
+
+    `setWorld` / `setCamera` upload once; `render*` calls can then be repeated without touching
+    host memory again (the benchmark and the multi-GPU driver rely on that).
+    """
+
+    def __init__(self, device=0):
+        self._lib = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._lib.rtow_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rtow_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def setWorld(self, world):
+        if isinstance(world, HittablesList):
+            world = world.flatten()
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+        cx, cy, cz, rad = f32(world["center_x"]), f32(world["center_y"]), f32(world["center_z"]), f32(world["radius"])
+        kind = np.ascontiguousarray(world["kind"], dtype=np.uint8)
+        albedo, fuzz, ir = f32(world["albedo"]), f32(world["fuzz"]), f32(world["ir"])
+        n = len(rad)
+        if not (len(cx) == len(cy) == len(cz) == len(kind) == len(fuzz) == len(ir) == n and albedo.shape == (n, 3)):
+            raise ValueError("setWorld: arrays of unequal length")
+        p = lambda a: a.ctypes.data if n else None  # noqa: E731
+        _lib.check(self._lib.rtow_set_scene(self._h, n, p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo), p(fuzz), p(ir)))
+        self.n_spheres = n
+
+    def setCamera(self, camera):
+        s = camera.to_struct() if isinstance(camera, Camera) else camera
+        _lib.check(self._lib.rtow_set_camera(self._h, C.byref(s)))
+
+    @staticmethod
+    def _rows(rows, height):
+        if rows is None:
+            return None, height, None
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        return r, len(r), (r.ctypes.data if len(r) else None)
+
+    def renderRows(self, width, height, samplesPerPixel, maxDepth, seed=RENDER_SEED, rows=None,
+                   want_accum=False, want_hit_id=False):
+        """Blocking render into host arrays: (rgb uint8 [n_rows,w,3], accum|None, hit_id|None)."""
+        keep, n_rows, rows_p = self._rows(rows, height)
+        rgb = np.empty((n_rows, width, 3), np.uint8)
+        acc = np.empty((n_rows, width, 3), np.uint64) if want_accum else None
+        hid = np.empty((n_rows, width), np.int32) if want_hit_id else None
+        if rows is not None and n_rows == 0:
+            rows_p = np.zeros(1, np.int32).ctypes.data
+        _lib.check(self._lib.rtow_render(
+            self._h, width, height, samplesPerPixel, maxDepth, seed, rows_p, n_rows,
+            rgb.ctypes.data if rgb.size else None,
+            acc.ctypes.data if acc is not None and acc.size else None,
+            hid.ctypes.data if hid is not None and hid.size else None))
+        return rgb, acc, hid
+
+    def renderAsync(self, width, height, samplesPerPixel, maxDepth, seed=RENDER_SEED, rows=None, rgb_dev=None):
+        """Enqueue a render whose 8-bit image stays on the device (rgb_dev: device address or None)."""
+        keep, n_rows, rows_p = self._rows(rows, height)
+        _lib.check(self._lib.rtow_render_async(self._h, width, height, samplesPerPixel, maxDepth, seed,
+                                               rows_p, n_rows, rgb_dev))
+
+    def sync(self):
+        _lib.check(self._lib.rtow_sync(self._h))
+
+    def stats(self):
+        s = _lib.Stats()
+        _lib.check(self._lib.rtow_get_stats(self._h, C.byref(s)))
+        return {"ray_segments": s.ray_segments, "paths": s.paths, "trace_ms": s.trace_ms,
+                "total_ms": s.total_ms, "n_spheres": s.n_spheres, "n_big": s.n_big}
+
+    def stream(self):
+        p = C.c_void_p()
+        _lib.check(self._lib.rtow_get_stream(self._h, C.byref(p)))
+        return p.value
+
+
+def writeColor(f, color, samplesPerPixel):
+    """raytracer.nim:22-28 for one pixel's colour sum (host side, binary64)."""
+    scale = 1.0 / float(samplesPerPixel)
+    r = math.sqrt(color.r * scale)
+    g = math.sqrt(color.g * scale)
+    b = math.sqrt(color.b * scale)
+    clamp = lambda x: min(max(x, 0.0), 0.999)  # noqa: E731
+    f.write(f"{int(256 * clamp(r))} {int(256 * clamp(g))} {int(256 * clamp(b))}\n")
+
+
+def writePPM(f, rgb):
+    """The P3 container of raytracer.nim:35,28: header, then one `r g b` line per pixel,
+    top row first."""
+    h, w, _ = rgb.shape
+    f.write(f"P3\n{w} {h}\n255\n")
+    flat = rgb.reshape(-1, 3)
+    f.write("\n".join(f"{p[0]} {p[1]} {p[2]}" for p in flat.tolist()))
+    f.write("\n")
+
+
+def render(img, f, world, camera, samplesPerPixel, maxDepth, seed=RENDER_SEED, device=0):
+    """render*(img, f, world, camera, samplesPerPixel, maxDepth) (raytracer.nim:30-46).
+
+    Writes the PPM file `f`; the pixel values come from the GPU.  Returns the image array too.
+    """
+    with Renderer(device) as r:
+        r.setWorld(world)
+        r.setCamera(camera)
+        rgb, _, _ = r.renderRows(img.width, img.height, samplesPerPixel, maxDepth, seed)
+    with open(f, "w") as out:
+        writePPM(out, rgb)
+    return rgb
+
+
+def sceneRedBlue():
+    """raytracer.nim:48-59"""
+    result = initHittables(0)
+    R = math.cos(math.pi / 4.0)
+    matLeft = initMaterial(initLambertian(color(0, 0, 1)))
+    matRight = initMaterial(initLambertian(color(1, 0, 0)))
+    result.add(Sphere(point(-R, 0, -1), R, matLeft))
+    result.add(Sphere(point(R, 0, -1), R, matRight))
+    return result
+
+
+def mixOfSpheres():
+    """raytracer.nim:61-73; the fourth sphere has a negative radius (a hollow glass shell)."""
+    result = initHittables(0)
+    matGround = initMaterial(initLambertian(color(0.8, 0.8, 0.0)))
+    matCenter = initMaterial(initLambertian(color(0.1, 0.2, 0.5)))
+    matLeft = initMaterial(initDielectric(1.5))
+    matRight = initMaterial(initMetal(color(0.8, 0.6, 0.2), 1.0))
+    result.add(Sphere(point(0, -100.5, -1), 100, matGround))
+    result.add(Sphere(point(0, 0, -1), 0.5, matCenter))
+    result.add(Sphere(point(-1.0, 0, -1), 0.5, matLeft))
+    result.add(Sphere(point(-1.0, 0, -1), -0.4, matLeft))
+    result.add(Sphere(point(1.0, 0, -1), 0.5, matRight))
+    return result
+
+
+def randomScene(halfExtent=11, lambertBelow=0.8, metalBelow=0.95, rng=None):
+    """raytracer.nim:75-111.  The defaults give the reference's 484-sphere scene; halfExtent and
+    the two material thresholds generalise it (a 101 x 101 grid, or an all metal/glass variant).
+    Draws come from the Nim generator in its un-seeded state unless `rng` is given, because the
+    reference builds the scene before it calls randomize (raytracer.nim:122 vs :135)."""
+    saved = nimrandom._global
+    nimrandom._global = rng if rng is not None else nimrandom.Rand()
+    try:
+        rand = nimrandom.rand
+        result = initHittables(0)
+        groundMaterial = initMaterial(initLambertian(color(0.5, 0.5, 0.5)))
+        result.add(Sphere(point(0, -1000, 0), 1000, groundMaterial))
+        for a in range(-halfExtent, halfExtent):
+            for b in range(-halfExtent, halfExtent):
+                chooseMat = rand(1.0)
+                cx = float(a) + 0.9 * rand(1.0)
+                cz = float(b) + 0.9 * rand(1.0)
+                center = point(cx, 0.2, cz)
+                if length(center - point(4, 0.2, 0)) > 0.9:
+                    if chooseMat < lambertBelow:
+                        first = randomVec()
+                        second = randomVec()
+                        albedo = Color(*(first * second))
+                        sphereMaterial = initMaterial(initLambertian(albedo))
+                    elif chooseMat < metalBelow:
+                        albedo = Color(*randomVec(0.5, 1.0))
+                        fuzz = rand(0.0, 0.5)
+                        sphereMaterial = initMaterial(initMetal(albedo, fuzz))
+                    else:
+                        sphereMaterial = initMaterial(initDielectric(1.5))
+                    result.add(Sphere(center, 0.2, sphereMaterial))
+        result.add(Sphere(point(0, 1, 0), 1.0, initMaterial(initDielectric(1.5))))
+        result.add(Sphere(point(-4, 1, 0), 1.0, initMaterial(initLambertian(color(0.4, 0.2, 0.1)))))
+        result.add(Sphere(point(4, 1, 0), 1.0, initMaterial(initMetal(color(0.7, 0.6, 0.5), 0.0))))
+        result.draws = nimrandom._global.draws
+        return result
+    finally:
+        nimrandom._global = saved
+
+
+def bookCamera(aspectRatio):
+    """The camera of main (raytracer.nim:125-132)."""
+    return initCamera(point(13, 2, 3), point(0, 0, 0), vec3(0, 1, 0), vfov=20, aspectRatio=aspectRatio,
+                      aperture=0.1, focusDist=10.0)
+
+
+def main(width=1200, ratio=3.0 / 2.0, samplesPerPixel=500, maxDepth=50, out="/tmp/test_small.ppm"):
+    """raytracer.nim:113-138 with its constants as defaults."""
+    img = Image(width, int(width / ratio))
+    world = randomScene()
+    cam = bookCamera(ratio)
+    render(img, out, world, cam, samplesPerPixel, maxDepth)
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:]]
+    if args:
+        main(width=int(args[0]), samplesPerPixel=int(args[1]) if len(args) > 1 else 500,
+             out=args[2] if len(args) > 2 else "/tmp/test_small.ppm")
+    else:
+        main()
