@@ -40,6 +40,29 @@ SYMBOLS = ["rtow_last_error", "rtow_version", "rtow_device_count", "rtow_create"
 _lib = None
 
 
+def _preload_hip_runtime():
+    """Make this process use ONE HIP runtime.
+
+    PyTorch wheels carry their own libamdhip64.so (same SONAME as /opt/rocm's).  If librtow_hip.so
+    pulled in the system copy first and torch then loaded its own, the second runtime would find
+    no GPU.  Loading torch's copy up front (when torch is installed) lets both resolve to it,
+    whichever is imported first; without torch the system runtime is used.
+    """
+    if os.environ.get("RTOW_SYSTEM_HIP_RUNTIME") == "1":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -48,6 +71,7 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C raytracinginoneweekend_amd/csrc` "
             "(or __graft_entry__.build()); this package has no CPU fallback")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rtow_last_error.restype = C.c_char_p

@@ -1,0 +1,301 @@
+"""GPU parity, through the C ABI (raytracer.Renderer -> librtow_hip.so).
+
+Bars:
+  * against the FP32 mirror (oracle/mirror32.c) and the committed fixtures: bit-exact - hit ids,
+    fixed-point radiance sums, 8-bit pixels and ray-segment counts, at any spp and depth;
+  * against the FP64 faithful restatement of the reference (oracle/ref64.c), same random streams:
+    PSNR >= 40 dB and mean absolute error <= 0.25 levels per channel on 8-bit images, primary
+    hit ids equal except on silhouette pixels (< 0.1 %).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return math.inf if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+def _R():
+    from raytracinginoneweekend_amd import raytracer
+    return raytracer
+
+
+def _world_from_oracle(oracle, arr, n):
+    return {
+        "center_x": [arr[j].center[0] for j in range(n)], "center_y": [arr[j].center[1] for j in range(n)],
+        "center_z": [arr[j].center[2] for j in range(n)], "radius": [arr[j].radius for j in range(n)],
+        "kind": [arr[j].kind for j in range(n)], "fuzz": [arr[j].fuzz for j in range(n)],
+        "ir": [arr[j].ir if arr[j].kind == oracle.DIELECTRIC else 1.0 for j in range(n)],
+        "albedo": np.array([list(arr[j].albedo) for j in range(n)], np.float32).reshape(n, 3),
+    }
+
+
+def _check_bit_exact(gpu, mirror):
+    rgb, acc, hid = gpu
+    m_rgb, m_acc, m_hid, _ = mirror
+    assert (hid == m_hid).all(), f"{np.sum(hid != m_hid)} primary hit ids differ"
+    assert (acc == m_acc).all(), f"{np.sum(acc != m_acc)} radiance sums differ"
+    assert (rgb == m_rgb).all(), f"{np.sum(rgb != m_rgb)} 8-bit values differ"
+
+
+def test_spp1_depth1_hit_ids_and_pixels_bit_exact(gpu_renderer, oracle, book_scene):
+    """The headline check: primary-ray hit ids and 8-bit pixels at spp=1, depth=1."""
+    arr, n = book_scene
+    R = _R()
+    for W, H in ((64, 48), (400, 225), (333, 127)):
+        gpu_renderer.setCamera(R.bookCamera(W / H))
+        got = gpu_renderer.renderRows(W, H, 1, 1, want_accum=True, want_hit_id=True)
+        ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, 1, 1)
+        _check_bit_exact(got, ref)
+        assert gpu_renderer.stats()["ray_segments"] == ref[3] == W * H
+    g = np.load(os.path.join(GOLDEN, "mirror32_64x48_spp1_d1.npz"))
+    gpu_renderer.setCamera(R.bookCamera(64 / 48))
+    rgb, acc, hid = gpu_renderer.renderRows(64, 48, 1, 1, want_accum=True, want_hit_id=True)
+    assert (rgb == g["rgb"]).all() and (hid == g["hit_id"]).all() and (acc == g["accum"]).all()
+
+
+def test_spp1_depth1_against_fp64_reference(gpu_renderer, oracle, book_scene):
+    """Same check against the FP64 restatement: identical except where the FP64 discriminant is
+    within FP32 rounding of zero (sphere silhouettes)."""
+    arr, n = book_scene
+    R = _R()
+    W, H = 400, 225
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    rgb, _, hid = gpu_renderer.renderRows(W, H, 1, 1, want_hit_id=True)
+    f_rgb, _, f_hid, _ = oracle.render_ref64(arr, n, oracle.book_camera(W / H), W, H, 1, 1)
+    bad = hid != f_hid
+    assert bad.mean() < 1e-3, f"{bad.sum()} of {bad.size} primary hits differ"
+    # where the hit agrees the sky colour is the same up to one quantisation step on the rare value
+    # that sits on a rounding boundary of 256*sqrt(x)
+    d = np.abs(rgb[~bad].astype(np.int32) - f_rgb[~bad].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-4
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(96, 64, 8, 50), (120, 80, 5, 3), (257, 65, 3, 50), (64, 64, 33, 2)])
+def test_full_paths_bit_exact_against_mirror(gpu_renderer, oracle, book_scene, W, H, spp, depth):
+    arr, n = book_scene
+    gpu_renderer.setCamera(_R().bookCamera(W / H))
+    got = gpu_renderer.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+    ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, spp, depth)
+    _check_bit_exact(got, ref)
+    assert gpu_renderer.stats()["ray_segments"] == ref[3]
+    assert gpu_renderer.stats()["paths"] == W * H * spp
+
+
+def test_committed_fixtures(gpu_renderer, oracle):
+    R = _R()
+    g = np.load(os.path.join(GOLDEN, "mirror32_96x64_spp8_d50.npz"))
+    gpu_renderer.setCamera(R.bookCamera(96 / 64))
+    rgb, acc, hid = gpu_renderer.renderRows(96, 64, 8, 50, want_accum=True, want_hit_id=True)
+    assert (rgb == g["rgb"]).all() and (acc == g["accum"]).all() and (hid == g["hit_id"]).all()
+    assert gpu_renderer.stats()["ray_segments"] == int(g["segments"])
+
+
+def test_mix_of_spheres_with_hollow_glass(oracle):
+    """mixOfSpheres (raytracer.nim:61-73): negative radius, fuzz 1.0 metal, radius-100 ground
+    (binary64 path), wide aperture."""
+    R = _R()
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    g = np.load(os.path.join(GOLDEN, "mirror32_mix_80x60_spp16_d50.npz"))
+    with R.Renderer(0) as r:
+        r.setWorld(R.mixOfSpheres())
+        r.setCamera(initCamera(point(3, 3, 2), point(0, 0, -1), vec3(0, 1, 0), 20.0, 80 / 60, aperture=2.0,
+                               focusDist=math.sqrt(27.0)))
+        rgb, acc, hid = r.renderRows(80, 60, 16, 50, want_accum=True, want_hit_id=True)
+        assert r.stats()["n_big"] == 1 and r.stats()["n_spheres"] == 5
+        assert (rgb == g["rgb"]).all() and (acc == g["accum"]).all() and (hid == g["hit_id"]).all()
+        assert r.stats()["ray_segments"] == int(g["segments"])
+
+
+def test_red_blue_and_empty_and_single(oracle):
+    R = _R()
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    cam = initCamera(point(0, 0, 0), point(0, 0, -1), vec3(0, 1, 0), 90.0, 2.0, aperture=0.0, focusDist=1.0)
+    ocam = oracle.book_camera(2.0, look_from=(0, 0, 0), look_at=(0, 0, -1), vfov=90.0, aperture=0.0, focus=1.0)
+    with R.Renderer(0) as r:
+        r.setCamera(cam)
+        r.setWorld(R.sceneRedBlue())
+        arr, n = oracle.red_blue()
+        _check_bit_exact(r.renderRows(64, 32, 16, 50, want_accum=True, want_hit_id=True),
+                         oracle.render_mirror32(arr, n, ocam, 64, 32, 16, 50))
+        # empty list: every path is one sky segment
+        from raytracinginoneweekend_amd.hittables import initHittables
+        r.setWorld(initHittables(0))
+        rgb, acc, hid = r.renderRows(40, 20, 4, 50, want_accum=True, want_hit_id=True)
+        empty, _ = oracle.spheres_from_arrays([], [], [], [], [], [])
+        _check_bit_exact((rgb, acc, hid), oracle.render_mirror32(empty, 0, ocam, 40, 20, 4, 50))
+        assert (hid == -1).all() and r.stats()["ray_segments"] == 40 * 20 * 4
+        # one sphere, nine spheres (padding of the table to a multiple of eight on both sides)
+        for count in (1, 8, 9):
+            arr, n = oracle.spheres_from_arrays([(0.3 * k - 1, 0, -1.5) for k in range(count)], [0.25] * count,
+                                                [k % 3 for k in range(count)], [(0.8, 0.5, 0.3)] * count,
+                                                [0.1] * count, [1.5] * count)
+            r.setWorld(_world_from_oracle(oracle, arr, n))
+            _check_bit_exact(r.renderRows(50, 25, 6, 50, want_accum=True, want_hit_id=True),
+                             oracle.render_mirror32(arr, n, ocam, 50, 25, 6, 50))
+
+
+def test_ties_go_to_later_index(oracle):
+    """Coincident spheres: the later list entry must win (hittables.nim:84-88)."""
+    R = _R()
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    arr, n = oracle.spheres_from_arrays([(0, 0, -2)] * 3 + [(0, -200.5, -2)] * 2, [0.5] * 3 + [200.0] * 2,
+                                        [0, 1, 0, 0, 0], [(0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9),
+                                                          (0.5, 0.5, 0.5), (0.2, 0.2, 0.2)], [0.0] * 5, [1.5] * 5)
+    ocam = oracle.book_camera(1.0, look_from=(0, 0, 0), look_at=(0, 0, -1), vfov=60.0, aperture=0.0, focus=1.0)
+    with R.Renderer(0) as r:
+        r.setCamera(initCamera(point(0, 0, 0), point(0, 0, -1), vec3(0, 1, 0), 60.0, 1.0, 0.0, 1.0))
+        r.setWorld(_world_from_oracle(oracle, arr, n))
+        got = r.renderRows(48, 48, 4, 8, want_accum=True, want_hit_id=True)
+        _check_bit_exact(got, oracle.render_mirror32(arr, n, ocam, 48, 48, 4, 8))
+        assert set(np.unique(got[2]).tolist()) <= {-1, 2, 4}
+        assert got[2][24, 24] == 2 and got[2][47, 24] == 4
+
+
+def test_converged_image_against_fp64_reference(gpu_renderer, oracle, book_scene):
+    """Tolerance check on a converged image: PSNR >= 40 dB, MAE <= 0.25 levels."""
+    arr, n = book_scene
+    R = _R()
+    W, H, spp = 200, 133, 128
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    rgb, acc, hid = gpu_renderer.renderRows(W, H, spp, 50, want_accum=True, want_hit_id=True)
+    f_rgb, f_acc, f_hid, f_seg = oracle.render_ref64(arr, n, oracle.book_camera(W / H), W, H, spp, 50, threads=16)
+    assert _psnr(rgb, f_rgb) >= 40.0, _psnr(rgb, f_rgb)
+    assert np.mean(np.abs(rgb.astype(np.int32) - f_rgb.astype(np.int32))) <= 0.25
+    assert np.mean(hid != f_hid) < 1e-3
+    assert abs(gpu_renderer.stats()["ray_segments"] - f_seg) / f_seg < 2e-3
+    lin = acc.astype(np.float64) / (spp * 2.0 ** 30)
+    assert abs(lin.mean() - (f_acc / spp).mean()) < 2e-4
+    # the committed FP64 fixture (100x67, spp 64)
+    g = np.load(os.path.join(GOLDEN, "ref64_100x67_spp64_d50.npz"))
+    gpu_renderer.setCamera(R.bookCamera(100 / 67))
+    rgb, _, hid = gpu_renderer.renderRows(100, 67, 64, 50, want_hit_id=True)
+    assert _psnr(rgb, g["rgb"]) >= 40.0
+    assert np.mean(np.abs(rgb.astype(np.int32) - g["rgb"].astype(np.int32))) <= 0.25
+
+
+def test_row_subsets_and_partition_invariance(gpu_renderer, oracle, book_scene):
+    """Any split of the rows gives byte-identical pixels (what makes 1/2/4/8-GPU images equal)."""
+    from raytracinginoneweekend_amd import multigpu
+    R = _R()
+    W, H, spp = 150, 100, 6
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    full = gpu_renderer.renderRows(W, H, spp, 50, want_accum=True, want_hit_id=True)
+    seg_full = gpu_renderer.stats()["ray_segments"]
+    for world in (2, 8):
+        seg = 0
+        for rank in range(world):
+            rows = multigpu.tile_rows(H, world, rank, tile=4)
+            part = gpu_renderer.renderRows(W, H, spp, 50, rows=rows, want_accum=True, want_hit_id=True)
+            for a, b in zip(part, full):
+                assert (a == b[rows]).all()
+            seg += gpu_renderer.stats()["ray_segments"]
+        assert seg == seg_full
+    rows = [99, 0, 50, 50]  # any order, duplicates allowed
+    part = gpu_renderer.renderRows(W, H, spp, 50, rows=rows)
+    assert (part[0] == full[0][rows]).all()
+    part = gpu_renderer.renderRows(W, H, spp, 50, rows=[])
+    assert part[0].shape == (0, W, 3)
+
+
+def test_repeatable_and_seed_dependent(gpu_renderer):
+    R = _R()
+    gpu_renderer.setCamera(R.bookCamera(1.5))
+    a = gpu_renderer.renderRows(90, 60, 4, 50, want_accum=True)
+    b = gpu_renderer.renderRows(90, 60, 4, 50, want_accum=True)
+    c = gpu_renderer.renderRows(90, 60, 4, 50, seed=0xE8, want_accum=True)
+    assert (a[1] == b[1]).all() and (a[0] == b[0]).all()
+    assert (a[1] != c[1]).any()
+    assert (a[0][0] == c[0][0]).all()  # sky row does not depend on the seed after quantisation
+
+
+def test_error_behaviour(gpu_renderer):
+    from raytracinginoneweekend_amd import _lib
+    R = _R()
+    gpu_renderer.setCamera(R.bookCamera(1.5))
+    for args in ((1, 10, 1, 1), (10, 1, 1, 1), (10, 10, 0, 1), (10, 10, 1, 0)):
+        with pytest.raises(_lib.RtowError) as e:
+            gpu_renderer.renderRows(*args)
+        assert e.value.status == -1
+    with pytest.raises(_lib.RtowError):
+        gpu_renderer.renderRows(10, 10, 1, 1, rows=[10])
+    with pytest.raises(_lib.RtowError):
+        gpu_renderer.renderRows(10, 10, 1, 1, rows=[-1])
+    with R.Renderer(0) as fresh:
+        with pytest.raises(_lib.RtowError) as e:
+            fresh.renderRows(10, 10, 1, 1)
+        assert e.value.status == -3
+        with pytest.raises(_lib.RtowError):
+            fresh.setWorld({"center_x": [0], "center_y": [0], "center_z": [0], "radius": [0.0], "kind": [0],
+                            "albedo": np.zeros((1, 3)), "fuzz": [0], "ir": [1.5]})
+        with pytest.raises(_lib.RtowError):
+            fresh.setWorld({"center_x": [0], "center_y": [0], "center_z": [0], "radius": [1.0], "kind": [3],
+                            "albedo": np.zeros((1, 3)), "fuzz": [0], "ir": [1.5]})
+    with pytest.raises(_lib.RtowError):
+        R.Renderer(4096)
+
+
+def test_full_size_properties(gpu_renderer, oracle, book_scene):
+    """1200x800 (the frame of the headline config) at low spp: properties that need no CPU render.
+    Sky rows reproduce the reference's own image; ray-segment bounds hold; two row bands add up."""
+    arr, n = book_scene
+    R = _R()
+    W, H, spp, depth = 1200, 800, 4, 50
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    rgb, acc, hid = gpu_renderer.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+    st = gpu_renderer.stats()
+    assert (rgb[0] == np.array([220, 235, 255], np.uint8)).all()      # media/rayTracing.png row 0
+    assert rgb[50, 600].tolist() == [221, 235, 255] and rgb[100, 100].tolist() == [222, 236, 255]
+    assert rgb[150, 1199].tolist() == [223, 236, 255]
+    assert st["paths"] == W * H * spp and st["paths"] <= st["ray_segments"] <= st["paths"] * depth
+    assert (hid[0] == -1).all() and hid.max() <= 483 and (hid[-1] >= 0).all() and hid[-1, 0] == 0  # bottom row: ground or a sphere
+    # a band of rows rendered alone equals the same rows of the full frame, and the oracle's
+    rows = [0, 399, 400, 799]
+    band = gpu_renderer.renderRows(W, H, spp, depth, rows=rows, want_accum=True)
+    assert (band[1] == acc[rows]).all()
+    m = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, spp, depth, rows=rows, threads=16)
+    assert (band[0] == m[0]).all() and (band[1] == m[1]).all()
+    # sums are bounded by spp * 2^30 per channel for this scene (all albedos <= 1)
+    assert acc.max() <= spp * 2 ** 30
+
+
+def test_async_device_resident_render(gpu_renderer):
+    import torch
+    R = _R()
+    W, H, spp = 128, 96, 3
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    host = gpu_renderer.renderRows(W, H, spp, 50)[0]
+    dev = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_renderer.renderAsync(W, H, spp, 50, rgb_dev=dev.data_ptr())
+    gpu_renderer.sync()
+    assert (dev.cpu().numpy() == host).all()
+    st = gpu_renderer.stats()
+    assert st["trace_ms"] > 0 and st["total_ms"] >= st["trace_ms"]
+
+
+def test_render_writes_reference_style_ppm(tmp_path, oracle, book_scene):
+    """render*(img, f, world, camera, spp, depth) end to end: the file is the P3 text the reference
+    writes (raytracer.nim:34-46) with the GPU's pixels."""
+    R = _R()
+    from raytracinginoneweekend_amd.basetypes import Image
+    arr, n = book_scene
+    out = str(tmp_path / "test_small.ppm")
+    img = Image(60, 40)
+    rgb = R.render(img, out, R.randomScene(), R.bookCamera(1.5), 2, 50)
+    tokens = open(out).read().split()
+    assert tokens[:4] == ["P3", "60", "40", "255"]
+    vals = np.array(tokens[4:], dtype=np.int64).reshape(40, 60, 3)
+    m = oracle.render_mirror32(arr, n, oracle.book_camera(1.5), 60, 40, 2, 50)
+    assert (vals == m[0]).all() and (rgb == m[0]).all()

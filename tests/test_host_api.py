@@ -1,0 +1,173 @@
+"""The host layer: the reference's module/proc surface (basetypes, hitrecord, hittables, camera,
+raytracer) and the C-ABI library it binds.  No GPU is needed: nothing here computes pixels."""
+import ctypes as C
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracinginoneweekend_amd as rt
+from raytracinginoneweekend_amd import _lib, basetypes as B, camera as cam_mod, hitrecord as HR, \
+    hittables as HT, multigpu, nimrandom, raytracer as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rtow.h")).read()
+    declared = sorted(set(re.findall(r"\b(rtow_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(_lib.SYMBOLS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.rtow_version() == 100
+    assert L.rtow_last_error() is not None
+
+
+def test_library_fails_loudly_without_a_gpu():
+    """No CPU fallback: on a box without a GPU context creation is an error with a message."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.RtowError) as e:
+        R.Renderer(0)
+    assert e.value.status in (-1, -2)
+    assert str(e.value)
+
+
+def test_null_arguments_are_rejected():
+    L = _lib.lib()
+    assert L.rtow_create(0, None) == -1
+    assert b"NULL" in L.rtow_last_error()
+    assert L.rtow_set_camera(None, None) == -1
+    assert L.rtow_render(None, 4, 4, 1, 1, 0, None, 4, None, None, None) == -1
+    assert L.rtow_sync(None) == -1
+    assert L.rtow_destroy(None) == 0
+
+
+def test_nimrandom_host_generator_matches_oracle(oracle):
+    g = nimrandom.Rand()
+    r = oracle.nim_default()
+    for _ in range(100):
+        assert g.next() == oracle.lib().orc_nimrand_next(C.byref(r))
+    g = nimrandom.Rand()
+    assert [g.rand(1.0) for _ in range(2)] == [0.23269614976095587, 0.8228467011541094]
+    for jump in (False, True):
+        h = nimrandom.initRand(0xE7, jump)
+        o = oracle.NimRand()
+        oracle.lib().orc_nimrand_init(C.byref(o), 0xE7, int(jump))
+        assert (h.a0, h.a1) == (o.a0, o.a1)
+    nimrandom.randomize(0xE7)
+    assert nimrandom.rand(1.0) == 8.605422641139171e-07
+    nimrandom.resetGlobal()
+    assert nimrandom.rand(-1.0, 1.0) == 0.23269614976095587 * 2.0 - 1.0
+
+
+def test_random_scene_host_equals_oracle(oracle):
+    w = R.randomScene()
+    arr, n, draws, _ = oracle.random_scene()
+    assert len(w) == n == 484 and w.draws == draws == 4026
+    for j in range(n):
+        s, h = arr[j], w[j].hSphere
+        kind, albedo, fuzz, ir = h.mat.flat()
+        assert list(s.center) == h.center.arr and s.radius == h.radius and s.kind == kind
+        if kind != HR.mkDielectric:
+            assert list(s.albedo) == list(albedo)
+        assert s.fuzz == fuzz
+        if kind == HR.mkDielectric:
+            assert s.ir == ir
+    # building a scene leaves the caller's global generator untouched
+    nimrandom.resetGlobal()
+    R.randomScene()
+    assert nimrandom.globalState().draws == 0
+
+
+def test_scene_variants():
+    big = R.randomScene(halfExtent=14)
+    assert 750 < len(big) <= 1 + 28 * 28 + 3
+    glassy = R.randomScene(lambertBelow=0.0, metalBelow=0.5)
+    kinds = [h.hSphere.mat.kind for h in glassy]
+    assert kinds[0] == HR.mkLambertian and kinds[-2] == HR.mkLambertian  # ground and big brown stay
+    assert HR.mkLambertian not in kinds[1:-3]
+    m = R.mixOfSpheres()
+    assert len(m) == 5 and m[3].hSphere.radius == -0.4
+    assert len(R.sceneRedBlue()) == 2
+
+
+def test_hittables_list_interface():
+    h = HT.initHittables(0)
+    assert h.size == 8 and len(h) == 0 and h.len == 0
+    s = HR.Sphere(B.point(1, 2, 3), 0.5, HR.initMaterial(HR.initMetal(B.color(0.1, 0.2, 0.3), 0.4)))
+    h.add(s)
+    h.add(HT.Hittable(HT.htSphere, HR.Sphere(B.point(0, 0, 0), -2.0, HR.initMaterial(HR.initDielectric(1.5)))))
+    assert len(h) == 2 and h[0].hSphere is s and [x.kind for x in h] == [HT.htSphere] * 2
+    with pytest.raises(AssertionError):
+        h[2]
+    with pytest.raises(TypeError):
+        h.add("sphere")
+    for _ in range(20):
+        h.add(s)
+    assert h.size > 22
+    f = h.flatten()
+    assert f["radius"].dtype == np.float32 and f["kind"].dtype == np.uint8 and f["albedo"].shape == (22, 3)
+    assert f["radius"][1] == -2.0 and f["kind"][1] == HR.mkDielectric and f["ir"][1] == 1.5
+    assert np.allclose(f["albedo"][0], [0.1, 0.2, 0.3]) and f["fuzz"][0] == np.float32(0.4)
+    assert HT.initHittables(0).flatten()["radius"].shape == (0,)
+    with pytest.raises(TypeError):
+        HR.initMaterial(object())
+
+
+def test_camera_host_equals_oracle(oracle):
+    for aspect in (1.5, 16 / 9, 1.0):
+        c = R.bookCamera(aspect)
+        o = oracle.book_camera(aspect)
+        for a, b in (("origin", "origin"), ("lower_left", "lowerLeftCorner"), ("horizontal", "horizontal"),
+                     ("vertical", "vertical"), ("u", "u"), ("v", "v"), ("w", "w")):
+            assert list(getattr(o, a)) == list(getattr(c, b))
+        assert o.lens_radius == c.lensRadius
+        s = c.to_struct()
+        assert s.origin[0] == 13.0 and abs(s.lens_radius - 0.05) < 1e-8
+    with pytest.raises(TypeError):
+        cam_mod.initCamera(B.point(0, 0, 0), B.point(0, 0, -1), B.vec3(0, 1, 0), 90, 2.0)
+
+
+def test_vec3_semantics():
+    v, u = B.vec3(1, 2, 3), B.vec3(4, 5, 6)
+    assert (v + u).arr == [5, 7, 9] and (u - v).arr == [3, 3, 3] and (v * u).arr == [4, 10, 18]
+    assert (2 * v).arr == [2, 4, 6] and (v / 2).arr == [0.5, 1, 1.5] and (6 / v).arr == [6, 3, 2]
+    assert B.dot(v, u) == 32 and B.cross(v, u).arr == [-3, 6, -3] and (-v).arr == [-1, -2, -3]
+    assert B.length_squared(v) == 14 and B.length(B.vec3(3, 4, 0)) == 5
+    assert isinstance(B.color(1, 0, 0) * B.color(0.5, 0.5, 0.5), B.Color) and B.color(1, 2, 3).g == 2
+    assert B.nearZero(B.vec3(1e-9, -1e-9, 0)) and not B.nearZero(B.vec3(1e-7, 0, 0))
+    assert B.reflect(B.vec3(1, -1, 0), B.vec3(0, 1, 0)).arr == [1, 1, 0]
+    assert B.initRay(B.point(1, 1, 1), B.vec3(0, 2, 0)).at(1.5).arr == [1, 4, 1]
+    t = B.refract(B.unitVector(B.vec3(1, -1, 0)), B.vec3(0, 1, 0), 1.0)
+    assert np.allclose(t.arr, B.unitVector(B.vec3(1, -1, 0)).arr)
+
+
+def test_ppm_writer_format():
+    rgb = np.array([[[255, 0, 1], [2, 3, 4]], [[5, 6, 7], [8, 9, 10]], [[0, 0, 0], [11, 12, 13]]], np.uint8)
+    f = io.StringIO()
+    R.writePPM(f, rgb)
+    assert f.getvalue() == "P3\n2 3\n255\n255 0 1\n2 3 4\n5 6 7\n8 9 10\n0 0 0\n11 12 13\n"
+    f = io.StringIO()
+    R.writeColor(f, B.color(250.0, 125.0, 0.0), 500)
+    assert f.getvalue() == "181 128 0\n"
+
+
+def test_tile_rows_partition():
+    for h, world, tile in ((800, 8, 4), (225, 4, 4), (67, 2, 3), (5, 8, 4), (2160, 8, 8)):
+        parts = [multigpu.tile_rows(h, world, r, tile) for r in range(world)]
+        allrows = np.sort(np.concatenate(parts))
+        assert (allrows == np.arange(h)).all()
+        assert max(len(p) for p in parts) == multigpu.padded_rows(h, world, tile)
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= tile
+    with pytest.raises(ValueError):
+        multigpu.tile_rows(10, 2, 2)
+
+
+def test_package_surface():
+    assert {"basetypes", "camera", "hitrecord", "hittables", "raytracer"} <= set(rt.__all__)
+    assert callable(rt.render) and callable(R.writeColor) and callable(cam_mod.initCamera)
