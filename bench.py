@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one full render of the headline frame (book-1 final scene, 1200x800, spp 500,
+depth 50, 484 spheres, seed 0xE7): clear + trace + resolve on the GPU with scene and camera
+already resident; nothing crosses PCIe inside the timed region except the 16-byte counter
+read-back.  With N > 1 (launched by torch.distributed.run, one process per GPU) the same frame
+is sharded by interleaved row tiles and each step ends with the RCCL gather of the 8-bit rows,
+so total work is fixed ("strong" scaling, BASELINE config 4).
+
+Prints ONE JSON line on rank 0.  value = ray segments (world.hit queries) of all ranks / wall
+seconds / 1e6.  roofline: algorithmic FLOP (18 per ray-sphere test, 18*N+65 per segment) over
+the trace kernel's own duration, measured with HIP events on the stream it runs on.
+cpu_baseline: the FP64 CPU restatement of the reference (oracle/, "port") timed on this box's
+host cores on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+FLOP_PER_TEST = 18             # hitrecord.nim:56-61: oc 3, half_b 5, |oc|^2 5, r*r 1, c 1, disc 3
+FLOP_PER_SEGMENT_EXTRA = 65    # a = |dir|^2 once, hit epilogue, scatter, sky (amortised)
+
+WORKLOADS = {
+    # name: (width, height, spp, depth, half_extent, lambert_below, metal_below)
+    "C2": (1200, 800, 500, 50, 11, 0.8, 0.95),
+    "C3": (1200, 800, 500, 50, 11, 0.0, 0.5),     # every small sphere metal or glass
+    "C5": (3840, 2160, 1024, 50, 50, 0.8, 0.95),  # ~10k spheres, brute force
+}
+
+
+def cpu_baseline(width, height, depth, seed):
+    """Time the FP64 restatement of the reference on a bounded sample: 16 rows spread over the
+    frame.  Single thread first (the reference is single-threaded), then all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    arr, n, _, _ = O.random_scene()
+    cam = O.book_camera(width / height)
+    rows = list(range(height // 32, height, height // 16))[:16]
+    spp = 256
+    t0 = time.perf_counter()
+    _, _, _, seg1 = O.render_ref64(arr, n, cam, width, height, spp, depth, seed=seed, rows=rows, threads=1)
+    t1 = time.perf_counter() - t0
+    cores = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    _, _, _, segm = O.render_ref64(arr, n, cam, width, height, 2 * spp, depth, seed=seed, rows=rows, threads=cores)
+    tm = time.perf_counter() - t0
+    return {
+        "value": seg1 / t1 / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+        "sample": f"oracle/ref64.c (FP64 restatement of the Nim reference, which cannot be built here), "
+                  f"{len(rows)} rows spread over the {width}x{height} frame, spp {spp}, depth {depth}, 1 thread, "
+                  f"{seg1} segments in {t1:.1f} s",
+        "value_all_cores": segm / tm / 1e6, "cores_all": cores,
+        "sample_all_cores": f"same rows, spp {2 * spp}, {cores} pthreads, {segm} segments in {tm:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    width, height, spp, depth, half_extent, lam, met = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    seed = 0xE7
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from raytracinginoneweekend_amd import multigpu, raytracer as R
+
+    world_scene = R.randomScene(halfExtent=half_extent, lambertBelow=lam, metalBelow=met)
+    n_spheres = len(world_scene)
+    r = R.Renderer(local_rank)
+    r.setWorld(world_scene)
+    r.setCamera(R.bookCamera(width / height))
+
+    tile = 4
+    rows = None if world == 1 else multigpu.tile_rows(height, world, rank, tile)
+    n_rows = height if rows is None else len(rows)
+    local_rgb = None
+    if world > 1:
+        local_rgb = torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{local_rank}")
+
+    def sync_all():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        r.renderAsync(width, height, spp, depth, seed, rows=rows,
+                      rgb_dev=None if local_rgb is None else local_rgb.data_ptr())
+        r.sync()
+        st = r.stats()
+        if world > 1:
+            multigpu.gather_image(local_rgb, height, width, world, rank, tile)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    segments = 0
+    trace_ms = []
+    total_ms = []
+    for _ in range(args.steps):
+        st = step()
+        segments += st["ray_segments"]
+        trace_ms.append(st["trace_ms"])
+        total_ms.append(st["total_ms"])
+    if world > 1:
+        torch.cuda.synchronize()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    seg_per_step_local = segments / max(1, args.steps)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([segments], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        segments = int(s.item())
+
+    if rank == 0:
+        flop_per_segment = FLOP_PER_TEST * n_spheres + FLOP_PER_SEGMENT_EXTRA
+        avg_trace_s = sum(trace_ms) / len(trace_ms) * 1e-3
+        achieved = seg_per_step_local * flop_per_segment / avg_trace_s / 1e12
+        paths = width * height * spp
+        out = {
+            "metric": "Mrays/sec (ray segments = world.hit queries) book-1 final scene 1200x800 spp500 depth50",
+            "value": segments / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(1, args.steps) * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (the reference's randomScene generator from its fixed default RNG state)",
+            "config": {
+                "workload": f"{args.workload}: book-1 random-spheres scene, {width}x{height}, spp {spp}, depth {depth}, "
+                            f"{n_spheres} spheres in a linear list, seed 0xE7",
+                "width": width, "height": height, "spp": spp, "max_depth": depth, "n_spheres": n_spheres,
+                "parallelism": "single GPU" if world == 1 else f"interleaved {tile}-row tiles over {world} GPUs + RCCL all_gather of 8-bit rows",
+                "paths_per_step": paths,
+                "segments_per_step": segments // max(1, args.steps),
+                "mean_segments_per_path": segments / max(1, args.steps) / paths,
+            },
+            "roofline": {
+                "bound": "valu_fp32",
+                "kernel": "rtow_trace_kernel",
+                "achieved": achieved,
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                # issue-rate ceilings measured on this chip by bench/ubench_valu.hip (profiles/)
+                "measured_peak_v_fma_f32": 126.8,
+                "measured_peak_v_pk_fma_f32": 147.7,
+                "flop_per_segment": flop_per_segment,
+                "kernel_ms": avg_trace_s * 1e3,
+                "traffic": None,
+                "framebuffer_GBps": (n_rows * width * 3) / (sum(total_ms) / len(total_ms) * 1e-3) / 1e9,
+            },
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(width, height, depth, seed)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
