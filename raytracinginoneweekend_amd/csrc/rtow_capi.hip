@@ -140,14 +140,19 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   HIP_TRY(hipStreamSynchronize(c->stream));  // a render may still be reading the old tables
 
   const int n_pad = ((n + rtow::kGeomPad - 1) / rtow::kGeomPad) * rtow::kGeomPad;
-  std::vector<float4> geom((size_t)(n_pad > 0 ? n_pad : 1));
+  // four spheres per 16-float group: cx0 cx1 cy0 cy1 cz0 cz1 rr0 rr1 | cx2 cx3 cy2 cy3 cz2 cz3 rr2 rr3
+  std::vector<float> geom((size_t)(n_pad > 0 ? n_pad : 4) * 4, 0.0f);
+  auto geom_at = [&geom](int j, int field) -> float& {
+    return geom[(size_t)(j / 4) * 16 + (size_t)((j % 4) / 2) * 8 + (size_t)field * 2 + (size_t)(j % 2)];
+  };
   std::vector<rtow::SphereShade> shade((size_t)(n > 0 ? n : 1));
   std::vector<rtow::BigSphere> big;
-  for (int j = 0; j < n_pad; ++j) geom[j] = make_float4(0.f, 0.f, 0.f, -INFINITY);
+  for (int j = 0; j < (n_pad > 0 ? n_pad : 4); ++j) geom_at(j, 3) = -INFINITY;
   for (int j = 0; j < n; ++j) {
     const float r = radius[j];
     const bool is_big = std::fabs(r) >= rtow::kBigRadius;
-    geom[j] = make_float4(cx[j], cy[j], cz[j], is_big ? -INFINITY : r * r);
+    geom_at(j, 0) = cx[j]; geom_at(j, 1) = cy[j]; geom_at(j, 2) = cz[j];
+    geom_at(j, 3) = is_big ? -INFINITY : r * r;
     if (is_big) {
       rtow::BigSphere b;
       b.cx = cx[j]; b.cy = cy[j]; b.cz = cz[j]; b.r = r; b.index = j; b.pad_ = 0;
@@ -158,10 +163,10 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     s.ar = albedo[3 * j]; s.ag = albedo[3 * j + 1]; s.ab = albedo[3 * j + 2]; s.fuzz = fuzz[j];
     s.kind = kind[j]; s.ir = ir[j]; s.inv_ir = 1.0f / ir[j]; s.pad_ = 0.f;
   }
-  HIP_TRY(c->geom.reserve(sizeof(float4) * geom.size()));
+  HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
   HIP_TRY(c->big.reserve(sizeof(rtow::BigSphere) * (big.empty() ? 1 : big.size())));
-  HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float4) * geom.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float) * geom.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice));
   if (!big.empty())
     HIP_TRY(hipMemcpy(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice));
@@ -214,7 +219,7 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
 
   rtow::TraceParams p;
   p.cam = c->cam;
-  p.geom = (const float4*)c->geom.p; p.n_geom_pad = c->n_geom_pad;
+  p.geom = (const float*)c->geom.p; p.n_geom_pad = c->n_geom_pad;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;
   p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth;

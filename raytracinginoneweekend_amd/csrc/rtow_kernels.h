@@ -10,7 +10,7 @@ constexpr int kGeomPad = 8;          // the regular sphere table is padded to a 
 
 struct TraceParams {
   CameraParams cam;
-  const float4* geom;        // n_geom_pad records (cx, cy, cz, r^2 | -inf), list order
+  const float* geom;         // n_geom_pad/4 groups of 16 floats (layout: scan_regular), list order
   int n_geom_pad;
   const BigSphere* big;      // spheres intersected in binary64
   int n_big;

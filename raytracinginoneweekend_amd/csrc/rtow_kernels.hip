@@ -10,36 +10,67 @@
 //  rtow_resolve_kernel mean + sqrt gamma + clamp + 8-bit quantisation (raytracer.nim:22-28).
 //
 // The sphere scan (hittables.nim:79-88 over hitrecord.nim:55-63) keeps the ray in VGPRs and
-// streams the sphere table through SGPRs with wave-uniform scalar loads: one 16-byte record
-// (cx, cy, cz, r^2) per sphere, 11 VALU instructions per ray-sphere test, and a rarely taken
-// branch for discriminant >= 0.
+// streams the sphere table through SGPRs with wave-uniform scalar loads, four spheres per load,
+// two spheres per packed FP32 instruction, and a rarely taken branch for discriminant >= 0.
 #include <hip/hip_runtime.h>
 #include "rtow_kernels.h"
 
 namespace rtow {
 
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef const f4v __attribute__((address_space(4)))* geom_ptr;  // constant address space: s_load
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+// constant address space: wave-uniform loads from it become s_load_dwordx16 into SGPRs
+typedef const f16v __attribute__((address_space(4)))* geom_ptr;
 
 static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Closest hit over the regular (binary32) table.  Entries of spheres handled elsewhere and the
-// padding carry r^2 = -inf, so their discriminant is never >= 0.
-static __device__ __forceinline__ void scan_regular(geom_ptr geom, int n_pad, f3 o, f3 u, float tmin,
+// Closest hit over the regular (binary32) table.
+//
+// The table is stored in groups of four spheres, 16 floats per group, as two packed pairs:
+//   cx0 cx1  cy0 cy1  cz0 cz1  rr0 rr1 | cx2 cx3  cy2 cy3  cz2 cz3  rr2 rr3     (rr = r^2)
+// One s_load_dwordx16 brings a group into SGPRs; the next group is requested before the current
+// one is tested.  Each pair is tested with packed FP32 instructions (v_pk_add/mul/fma_f32: two
+// spheres per instruction, the ray component broadcast to both halves), and one comparison on
+// the maximum of the four discriminants decides whether any lane has a candidate.  Entries of
+// spheres handled elsewhere and the padding carry r^2 = -inf, so their discriminant is never >= 0.
+// Per sphere the arithmetic is exactly: oc = o - c; b = fma(oc.z,u.z, fma(oc.y,u.y, oc.x*u.x));
+// disc = fma(b,b, fma(-oc.z,oc.z, fma(-oc.y,oc.y, fma(-oc.x,oc.x, r^2)))).
+static __device__ __forceinline__ void pair_test(const f2v cx, const f2v cy, const f2v cz, const f2v rr,
+                                                 const f2v ox, const f2v oy, const f2v oz, const f2v ux,
+                                                 const f2v uy, const f2v uz, f2v& b, f2v& disc) {
+  const f2v ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+  b = ocx * ux;
+  b = __builtin_elementwise_fma(ocy, uy, b);
+  b = __builtin_elementwise_fma(ocz, uz, b);
+  f2v m = __builtin_elementwise_fma(-ocx, ocx, rr);
+  m = __builtin_elementwise_fma(-ocy, ocy, m);
+  m = __builtin_elementwise_fma(-ocz, ocz, m);
+  disc = __builtin_elementwise_fma(b, b, m);
+}
+
+static __device__ __forceinline__ void scan_regular(geom_ptr geom, int n_groups, f3 o, f3 u, float tmin,
                                                     int prev, float& best, int& id) {
-#pragma unroll 4
-  for (int j = 0; j < n_pad; ++j) {
-    const f4v s = geom[j];
-    const float ocx = o.x - s.x, ocy = o.y - s.y, ocz = o.z - s.z;
-    float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
-    float m = fmaf(-ocx, ocx, s.w); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
-    const float disc = fmaf(b, b, m);
-    if (disc >= 0.0f) {
+  if (n_groups <= 0) return;
+  const f2v ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const f2v ux = {u.x, u.x}, uy = {u.y, u.y}, uz = {u.z, u.z};
+  f16v cur = geom[0];
+  for (int g = 0; g < n_groups; ++g) {
+    const f16v nxt = geom[g + 1 < n_groups ? g + 1 : g];
+    f2v b0, d0, b1, d1;
+    pair_test(cur.s01, cur.s23, cur.s45, cur.s67, ox, oy, oz, ux, uy, uz, b0, d0);
+    pair_test(cur.s89, cur.sab, cur.scd, cur.sef, ox, oy, oz, ux, uy, uz, b1, d1);
+    const float mx = fmaxf(fmaxf(d0.x, d0.y), fmaxf(d1.x, d1.y));
+    if (mx >= 0.0f) {
+      const int j = 4 * g;
       float t;
-      if (regular_candidate(b, disc, tmin, j == prev, t)) offer(t, j, best, id);
+      if (d0.x >= 0.0f && regular_candidate(b0.x, d0.x, tmin, j == prev, t)) offer(t, j, best, id);
+      if (d0.y >= 0.0f && regular_candidate(b0.y, d0.y, tmin, j + 1 == prev, t)) offer(t, j + 1, best, id);
+      if (d1.x >= 0.0f && regular_candidate(b1.x, d1.x, tmin, j + 2 == prev, t)) offer(t, j + 2, best, id);
+      if (d1.y >= 0.0f && regular_candidate(b1.y, d1.y, tmin, j + 3 == prev, t)) offer(t, j + 3, best, id);
     }
+    cur = nxt;
   }
 }
 
@@ -125,7 +156,7 @@ __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TracePa
         float t;
         if (big_candidate(o, u, bs, tmin, bs.index == prev, t)) offer(t, bs.index, best, id);
       }
-      scan_regular(geom, P.n_geom_pad, o, u, tmin, prev, best, id);
+      scan_regular(geom, P.n_geom_pad / 4, o, u, tmin, prev, best, id);
 
       if (P.hit_id && first_sample && depth == P.max_depth) P.hit_id[accpix] = id;
 
