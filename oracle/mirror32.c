@@ -17,6 +17,11 @@
  *   - spheres with |radius| >= 100 (the 1000-unit ground sphere, raytracer.nim:79) are
  *     intersected in binary64 from the binary32 ray, because |oc|^2 - r^2 cancels
  *     catastrophically in binary32; all other spheres use binary32 only;
+ *   - every binary32 sphere is first screened by a cheaper evaluation of its discriminant,
+ *     n^2 + (2o).c - k >= |o|^2 - 2^-19 (|o| + cmax)^2 with n = c.u - o.u and k = |c|^2 - r^2,
+ *     and only spheres that pass get the exact test below (the screen is there because the GPU
+ *     evaluates it for two spheres per packed instruction; its margin is several times the
+ *     rounding error of both evaluations, so in practice it only removes non-candidates);
  *   - a ray that starts on sphere j (it was scattered there) meets j again only at the
  *     analytic far root t = -2 (oc.u): the near root is 0 by construction and is dropped, which
  *     removes the binary32 self-intersections that t_min = 0.001|d| cannot catch when the
@@ -39,7 +44,8 @@ static inline float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x 
 
 typedef struct {
   float cx, cy, cz, r;  /* binary32 roundings of the scene description */
-  float r2;             /* r*r, or -inf for spheres taken by the binary64 path */
+  float r2;             /* r*r */
+  float k;              /* |c|^2 - r^2, evaluated in binary64 and rounded once (filter operand) */
   float inv_r;          /* 1/r */
   int big;
   int kind;
@@ -53,16 +59,26 @@ typedef struct {
 } cam32;
 
 #define BIG_RADIUS 100.0f
+#define FILTER_MARGIN (1.0f / 524288.0f) /* 2^-19 */
 #define FIX_ONE 1073741824.0f /* 2^30 */
 #define RADIANCE_CLAMP 3.5f
 
-static void prep_scene(const orc_sphere* in, int n, sph32* out) {
+static void prep_scene(const orc_sphere* in, int n, sph32* out, float* cmax) {
+  *cmax = 0.0f;
   for (int j = 0; j < n; ++j) {
     sph32 s;
     s.cx = (float)in[j].center[0]; s.cy = (float)in[j].center[1]; s.cz = (float)in[j].center[2];
     s.r = (float)in[j].radius;
     s.big = fabsf(s.r) >= BIG_RADIUS;
-    s.r2 = s.big ? -INFINITY : s.r * s.r;
+    s.r2 = s.r * s.r;
+    {
+      const double c2 = (double)s.cx * s.cx + (double)s.cy * s.cy + (double)s.cz * s.cz;
+      s.k = (float)(c2 - (double)s.r * s.r);
+      if (!s.big) {
+        const float reach = (float)sqrt(c2) + fabsf(s.r);
+        if (reach > *cmax) *cmax = reach;
+      }
+    }
     s.inv_r = 1.0f / s.r;
     s.kind = in[j].kind;
     s.ar = (float)in[j].albedo[0]; s.ag = (float)in[j].albedo[1]; s.ab = (float)in[j].albedo[2];
@@ -102,12 +118,22 @@ static inline f3 unit_ball(stream* g, float* l2_out) {
 /* closest hit over the whole list: candidate of a sphere is its near root if >= tmin, else its
  * far root if >= tmin (hitrecord.nim:66-71); minimum wins, ties go to the later index
  * (hittables.nim:84-88) */
-static int closest_hit(const sph32* w, int n, f3 o, f3 u, float tmin, int prev, float* t_out) {
+static int closest_hit(const sph32* w, int n, float cmax, f3 o, f3 u, float tmin, int prev, float* t_out) {
   float best = INFINITY;
   int id = -1;
+  /* per-ray operands of the filter that screens every binary32 sphere:
+   *   n^2 + (2o).c - k >= |o|^2 - margin,  n = c.u - o.u,  margin = 2^-19 (|o| + cmax)^2 */
+  const float nou = -dot3(o, u);
+  const float ox2 = 2.0f * o.x, oy2 = 2.0f * o.y, oz2 = 2.0f * o.z;
+  const float oo = dot3(o, o);
+  const float reach = sqrtf(oo) + cmax;
+  const float threshold = oo - FILTER_MARGIN * (reach * reach);
   for (int j = 0; j < n; ++j) {
     float t;
     if (!w[j].big) {
+      float fn = fmaf(w[j].cx, u.x, nou); fn = fmaf(w[j].cy, u.y, fn); fn = fmaf(w[j].cz, u.z, fn);
+      float ft = w[j].cx * ox2; ft = fmaf(w[j].cy, oy2, ft); ft = fmaf(w[j].cz, oz2, ft);
+      if (!(fmaf(fn, fn, ft) - w[j].k >= threshold)) continue;
       const float ocx = o.x - w[j].cx, ocy = o.y - w[j].cy, ocz = o.z - w[j].cz;
       float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
       float m = fmaf(-ocx, ocx, w[j].r2); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
@@ -152,7 +178,7 @@ static int closest_hit(const sph32* w, int n, f3 o, f3 u, float tmin, int prev, 
 }
 
 typedef struct {
-  const sph32* w; int n; const cam32* cam;
+  const sph32* w; int n; float cmax; const cam32* cam;
   int W, H, spp, max_depth; uint64_t seed;
   const int32_t* rows; int n_rows; atomic_int* next_row;
   uint8_t* rgb; uint64_t* accum; int32_t* hit_id; uint64_t segments;
@@ -198,7 +224,7 @@ static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t s
     const f3 u = {d.x * il, d.y * il, d.z * il};
     const float tmin = 0.001f * len;
     float t;
-    const int id = closest_hit(jb->w, jb->n, o, u, tmin, prev, &t);
+    const int id = closest_hit(jb->w, jb->n, jb->cmax, o, u, tmin, prev, &t);
     if (depth == jb->max_depth) *first_id = id;
     if (trail) { if (*trail_len < trail_cap) trail[*trail_len] = id; ++*trail_len; }
     if (id < 0) { /* sky, raytracer.nim:18-20 */
@@ -304,7 +330,8 @@ int orc_mirror32_render(const orc_sphere* spheres, int n_spheres, const orc_came
                         uint64_t* ray_segments) {
   if (W < 2 || H < 2 || spp < 1 || n_rows < 0 || n_spheres < 0) return -1;
   sph32* w = (sph32*)malloc(sizeof(sph32) * (size_t)(n_spheres > 0 ? n_spheres : 1));
-  prep_scene(spheres, n_spheres, w);
+  float cmax;
+  prep_scene(spheres, n_spheres, w, &cmax);
   cam32 c;
   prep_camera(cam, &c);
   if (n_threads < 1) n_threads = 1;
@@ -313,7 +340,7 @@ int orc_mirror32_render(const orc_sphere* spheres, int n_spheres, const orc_came
   pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
   atomic_int next_row = 0;
   for (int t = 0; t < n_threads; ++t) {
-    job32 jb = {w, n_spheres, &c, W, H, spp, max_depth, seed, rows, n_rows, &next_row,
+    job32 jb = {w, n_spheres, cmax, &c, W, H, spp, max_depth, seed, rows, n_rows, &next_row,
                 rgb, accum_fix, hit_id, 0};
     jobs[t] = jb;
   }
@@ -335,10 +362,11 @@ int orc_mirror32_trace_path(const orc_sphere* spheres, int n_spheres, const orc_
                             int max_depth, uint64_t seed, int i, int y, int sample, int32_t* trail,
                             int trail_cap, uint64_t fix[3]) {
   sph32* w = (sph32*)malloc(sizeof(sph32) * (size_t)(n_spheres > 0 ? n_spheres : 1));
-  prep_scene(spheres, n_spheres, w);
+  float cmax;
+  prep_scene(spheres, n_spheres, w, &cmax);
   cam32 c;
   prep_camera(cam, &c);
-  job32 jb = {w, n_spheres, &c, W, H, 1, max_depth, seed, NULL, 0, NULL, NULL, NULL, NULL, 0};
+  job32 jb = {w, n_spheres, cmax, &c, W, H, 1, max_depth, seed, NULL, 0, NULL, NULL, NULL, NULL, 0};
   int first, len = 0;
   uint64_t seg = 0, f[3];
   trace_path(&jb, i, H - 1 - y, (uint32_t)(y * W + i), (uint32_t)sample, f, &first, &seg, trail, trail_cap, &len);

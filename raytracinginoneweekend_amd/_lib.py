@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtow_hip.so")
+# RTOW_LIB_PATH selects an alternative build of the same ABI (instrumented builds for profiling)
+LIB_PATH = os.environ.get("RTOW_LIB_PATH") or os.path.join(_HERE, "lib", "librtow_hip.so")
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 
@@ -63,16 +64,14 @@ def _preload_hip_runtime():
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path):
+    """dlopen one build of the library and declare its prototypes."""
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `make -C raytracinginoneweekend_amd/csrc` "
+            f"{path} is missing: build it with `make -C raytracinginoneweekend_amd/csrc` "
             "(or __graft_entry__.build()); this package has no CPU fallback")
     _preload_hip_runtime()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.rtow_last_error.restype = C.c_char_p
     L.rtow_last_error.argtypes = []
@@ -87,8 +86,14 @@ def lib():
     L.rtow_sync.argtypes = [vp]
     L.rtow_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rtow_get_stream.argtypes = [vp, C.POINTER(vp)]
-    _lib = L
     return L
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load(LIB_PATH)
+    return _lib
 
 
 def check(status):

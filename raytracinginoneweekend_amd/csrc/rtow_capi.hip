@@ -60,7 +60,8 @@ struct rtow_ctx {
   // scene
   bool have_scene = false, have_camera = false;
   int n_spheres = 0, n_geom_pad = 0, n_big = 0;
-  DevBuf geom, big, shade;
+  DevBuf geom, geom_rr, big, shade;
+  float cmax = 0.0f;
   rtow::CameraParams cam;
 
   // per-render workspace
@@ -115,7 +116,7 @@ int rtow_destroy(rtow_ctx* c) {
   if (!c) return RTOW_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->geom.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
+  c->geom.release(); c->geom_rr.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   if (c->host_counters) (void)hipHostFree(c->host_counters);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -140,19 +141,30 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   HIP_TRY(hipStreamSynchronize(c->stream));  // a render may still be reading the old tables
 
   const int n_pad = ((n + rtow::kGeomPad - 1) / rtow::kGeomPad) * rtow::kGeomPad;
-  // four spheres per 16-float group: cx0 cx1 cy0 cy1 cz0 cz1 rr0 rr1 | cx2 cx3 cy2 cy3 cz2 cz3 rr2 rr3
-  std::vector<float> geom((size_t)(n_pad > 0 ? n_pad : 4) * 4, 0.0f);
+  // four spheres per 16-float group: cx0 cx1 cy0 cy1 cz0 cz1 k0 k1 | cx2 cx3 cy2 cy3 cz2 cz3 k2 k3
+  // with k = |c|^2 - r^2 (+inf: never passes the filter)
+  // plus one all-padding group behind the last one (the scan prefetches past the end)
+  const int n_alloc = n_pad + 4;
+  std::vector<float> geom((size_t)n_alloc * 4, 0.0f);
   auto geom_at = [&geom](int j, int field) -> float& {
     return geom[(size_t)(j / 4) * 16 + (size_t)((j % 4) / 2) * 8 + (size_t)field * 2 + (size_t)(j % 2)];
   };
   std::vector<rtow::SphereShade> shade((size_t)(n > 0 ? n : 1));
   std::vector<rtow::BigSphere> big;
-  for (int j = 0; j < (n_pad > 0 ? n_pad : 4); ++j) geom_at(j, 3) = -INFINITY;
+  for (int j = 0; j < n_alloc; ++j) geom_at(j, 3) = INFINITY;
+  std::vector<float> rr((size_t)n_alloc, 0.0f);
+  float cmax = 0.0f;
   for (int j = 0; j < n; ++j) {
     const float r = radius[j];
     const bool is_big = std::fabs(r) >= rtow::kBigRadius;
     geom_at(j, 0) = cx[j]; geom_at(j, 1) = cy[j]; geom_at(j, 2) = cz[j];
-    geom_at(j, 3) = is_big ? -INFINITY : r * r;
+    if (!is_big) {
+      const double c2 = (double)cx[j] * cx[j] + (double)cy[j] * cy[j] + (double)cz[j] * cz[j];
+      geom_at(j, 3) = (float)(c2 - (double)r * r);
+      rr[j] = r * r;
+      const float reach = (float)std::sqrt(c2) + std::fabs(r);
+      if (reach > cmax) cmax = reach;
+    }
     if (is_big) {
       rtow::BigSphere b;
       b.cx = cx[j]; b.cy = cy[j]; b.cz = cz[j]; b.r = r; b.index = j; b.pad_ = 0;
@@ -164,9 +176,12 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     s.kind = kind[j]; s.ir = ir[j]; s.inv_ir = 1.0f / ir[j]; s.pad_ = 0.f;
   }
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
+  HIP_TRY(c->geom_rr.reserve(sizeof(float) * rr.size()));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
   HIP_TRY(c->big.reserve(sizeof(rtow::BigSphere) * (big.empty() ? 1 : big.size())));
   HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float) * geom.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->geom_rr.p, rr.data(), sizeof(float) * rr.size(), hipMemcpyHostToDevice));
+  c->cmax = cmax;
   HIP_TRY(hipMemcpy(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice));
   if (!big.empty())
     HIP_TRY(hipMemcpy(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice));
@@ -219,7 +234,8 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
 
   rtow::TraceParams p;
   p.cam = c->cam;
-  p.geom = (const float*)c->geom.p; p.n_geom_pad = c->n_geom_pad;
+  p.geom = (const float*)c->geom.p; p.geom_rr = (const float*)c->geom_rr.p; p.n_geom_pad = c->n_geom_pad;
+  p.cmax = c->cmax;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;
   p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth;

@@ -11,7 +11,9 @@ constexpr int kGeomPad = 8;          // the regular sphere table is padded to a 
 struct TraceParams {
   CameraParams cam;
   const float* geom;         // n_geom_pad/4 groups of 16 floats (layout: scan_regular), list order
+  const float* geom_rr;      // r^2 per list entry (n_geom_pad values), for the exact test
   int n_geom_pad;
+  float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin
   const BigSphere* big;      // spheres intersected in binary64
   int n_big;
   const SphereShade* shade;  // one record per list entry

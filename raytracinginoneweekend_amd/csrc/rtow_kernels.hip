@@ -17,66 +17,114 @@
 
 namespace rtow {
 
+#ifdef RTOW_PROFILE_COUNTERS
+// debug build only: [0] wave-level group slow-path entries, [1] wave-level candidate evaluations,
+// [2] lane-level candidate evaluations, [3] wave iterations, [4] lane iterations (alive lanes)
+__device__ unsigned long long g_prof[8];
+#define RTOW_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1))) atomicAdd(&g_prof[i], v_); } while (0)
+#else
+#define RTOW_COUNT(i, v) do { } while (0)
+#endif
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 // constant address space: wave-uniform loads from it become s_load_dwordx16 into SGPRs
 typedef const f16v __attribute__((address_space(4)))* geom_ptr;
+typedef const float __attribute__((address_space(4)))* rr_ptr;
+
+// per-ray operands of the packed filter, every component duplicated into both halves of a pair
+struct ScanRay {
+  f2v ux, uy, uz, nou;     // unit direction, -(o.u)
+  f2v ox2, oy2, oz2;       // 2*o
+  float threshold;         // |o|^2 - margin
+};
+
+static __device__ __forceinline__ ScanRay scan_ray(f3 o, f3 u, float cmax) {
+  ScanRay r;
+  const FilterRay f = filter_ray(o, u, cmax);
+  r.ux = f2v{u.x, u.x}; r.uy = f2v{u.y, u.y}; r.uz = f2v{u.z, u.z};
+  r.nou = f2v{f.nou, f.nou};
+  r.ox2 = f2v{f.ox2, f.ox2}; r.oy2 = f2v{f.oy2, f.oy2}; r.oz2 = f2v{f.oz2, f.oz2};
+  r.threshold = f.threshold;
+  return r;
+}
 
 static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Closest hit over the regular (binary32) table.
+// Closest hit over the regular (binary32) table: a cheap packed filter over every sphere, and the
+// exact Sphere.hit arithmetic (hitrecord.nim:56-63) only for the spheres the filter lets through.
+//
+// Filter.  With n = c.u - o.u and k = |c|^2 - r^2 the discriminant is
+//     disc = n^2 - (k + |o|^2 - 2 o.c),
+// so  disc >= -margin  <=>  n^2 + (2o).c - k >= |o|^2 - margin.   The left side costs eight
+// packed instructions per PAIR of spheres (no per-sphere subtraction of the centre), the right
+// side is one number per ray.  Rounding makes the filter value differ from the exact
+// discriminant by a few ulps of (|o| + |c|)^2, which `margin` (ScanRay::threshold) covers; a sphere
+// that passes is then tested exactly, so the filter only ever adds work, never hits.
 //
 // The table is stored in groups of four spheres, 16 floats per group, as two packed pairs:
-//   cx0 cx1  cy0 cy1  cz0 cz1  rr0 rr1 | cx2 cx3  cy2 cy3  cz2 cz3  rr2 rr3     (rr = r^2)
-// One s_load_dwordx16 brings a group into SGPRs; the next group is requested before the current
-// one is tested.  Each pair is tested with packed FP32 instructions (v_pk_add/mul/fma_f32: two
-// spheres per instruction, the ray component broadcast to both halves), and one comparison on
-// the maximum of the four discriminants decides whether any lane has a candidate.  Entries of
-// spheres handled elsewhere and the padding carry r^2 = -inf, so their discriminant is never >= 0.
-// Per sphere the arithmetic is exactly: oc = o - c; b = fma(oc.z,u.z, fma(oc.y,u.y, oc.x*u.x));
-// disc = fma(b,b, fma(-oc.z,oc.z, fma(-oc.y,oc.y, fma(-oc.x,oc.x, r^2)))).
-static __device__ __forceinline__ void pair_test(const f2v cx, const f2v cy, const f2v cz, const f2v rr,
-                                                 const f2v ox, const f2v oy, const f2v oz, const f2v ux,
-                                                 const f2v uy, const f2v uz, f2v& b, f2v& disc) {
-  const f2v ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-  b = ocx * ux;
-  b = __builtin_elementwise_fma(ocy, uy, b);
-  b = __builtin_elementwise_fma(ocz, uz, b);
-  f2v m = __builtin_elementwise_fma(-ocx, ocx, rr);
-  m = __builtin_elementwise_fma(-ocy, ocy, m);
-  m = __builtin_elementwise_fma(-ocz, ocz, m);
-  disc = __builtin_elementwise_fma(b, b, m);
+//   cx0 cx1  cy0 cy1  cz0 cz1  k0 k1 | cx2 cx3  cy2 cy3  cz2 cz3  k2 k3
+// One s_load_dwordx16 brings a group into SGPRs, two groups ahead of its use.  Spheres handled
+// elsewhere and the padding carry k = +inf, so they never pass.  r^2 for the exact test comes from
+// a separate array, fetched only when needed.
+static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, const f2v cz, const f2v k,
+                                                  const ScanRay& r) {
+  f2v n = __builtin_elementwise_fma(cx, r.ux, r.nou);
+  n = __builtin_elementwise_fma(cy, r.uy, n);
+  n = __builtin_elementwise_fma(cz, r.uz, n);
+  f2v t = cx * r.ox2;
+  t = __builtin_elementwise_fma(cy, r.oy2, t);
+  t = __builtin_elementwise_fma(cz, r.oz2, t);
+  return __builtin_elementwise_fma(n, n, t) - k;
 }
 
-static __device__ __forceinline__ void scan_regular(geom_ptr geom, int n_groups, f3 o, f3 u, float tmin,
-                                                    int prev, float& best, int& id) {
+static __device__ __forceinline__ void exact_test(float cx, float cy, float cz, float rr, int j, f3 o, f3 u,
+                                                  float tmin, int prev, float& best, int& id) {
+  const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+  float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
+  float m = fmaf(-ocx, ocx, rr); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
+  const float disc = fmaf(b, b, m);
+  float t;
+  if (disc >= 0.0f && regular_candidate(b, disc, tmin, j == prev, t)) offer(t, j, best, id);
+}
+
+static __device__ __forceinline__ void group_test(const f16v grp, int j, rr_ptr rr, const ScanRay& r, f3 o,
+                                                  f3 u, float tmin, int prev, float& best, int& id) {
+  const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, grp.s67, r);
+  const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, grp.sef, r);
+  const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
+  if (mx >= r.threshold) {
+    RTOW_COUNT(0, 1);
+    RTOW_COUNT(1, (__ballot(f0.x >= r.threshold) != 0) + (__ballot(f0.y >= r.threshold) != 0) + (__ballot(f1.x >= r.threshold) != 0) + (__ballot(f1.y >= r.threshold) != 0));
+    RTOW_COUNT(2, __popcll(__ballot(f0.x >= r.threshold)) + __popcll(__ballot(f0.y >= r.threshold)) + __popcll(__ballot(f1.x >= r.threshold)) + __popcll(__ballot(f1.y >= r.threshold)));
+    if (f0.x >= r.threshold) exact_test(grp.s0, grp.s2, grp.s4, rr[j], j, o, u, tmin, prev, best, id);
+    if (f0.y >= r.threshold) exact_test(grp.s1, grp.s3, grp.s5, rr[j + 1], j + 1, o, u, tmin, prev, best, id);
+    if (f1.x >= r.threshold) exact_test(grp.s8, grp.sa, grp.sc, rr[j + 2], j + 2, o, u, tmin, prev, best, id);
+    if (f1.y >= r.threshold) exact_test(grp.s9, grp.sb, grp.sd, rr[j + 3], j + 3, o, u, tmin, prev, best, id);
+  }
+}
+
+// n_groups is even and the table holds one more (all-padding) group after the last one, so the
+// loop can always request two groups ahead without a bounds test.
+static __device__ __forceinline__ void scan_regular(geom_ptr geom, rr_ptr rr, int n_groups, float cmax, f3 o,
+                                                    f3 u, float tmin, int prev, float& best, int& id) {
   if (n_groups <= 0) return;
-  const f2v ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-  const f2v ux = {u.x, u.x}, uy = {u.y, u.y}, uz = {u.z, u.z};
-  f16v cur = geom[0];
-  for (int g = 0; g < n_groups; ++g) {
-    const f16v nxt = geom[g + 1 < n_groups ? g + 1 : g];
-    f2v b0, d0, b1, d1;
-    pair_test(cur.s01, cur.s23, cur.s45, cur.s67, ox, oy, oz, ux, uy, uz, b0, d0);
-    pair_test(cur.s89, cur.sab, cur.scd, cur.sef, ox, oy, oz, ux, uy, uz, b1, d1);
-    const float mx = fmaxf(fmaxf(d0.x, d0.y), fmaxf(d1.x, d1.y));
-    if (mx >= 0.0f) {
-      const int j = 4 * g;
-      float t;
-      if (d0.x >= 0.0f && regular_candidate(b0.x, d0.x, tmin, j == prev, t)) offer(t, j, best, id);
-      if (d0.y >= 0.0f && regular_candidate(b0.y, d0.y, tmin, j + 1 == prev, t)) offer(t, j + 1, best, id);
-      if (d1.x >= 0.0f && regular_candidate(b1.x, d1.x, tmin, j + 2 == prev, t)) offer(t, j + 2, best, id);
-      if (d1.y >= 0.0f && regular_candidate(b1.y, d1.y, tmin, j + 3 == prev, t)) offer(t, j + 3, best, id);
-    }
-    cur = nxt;
+  const ScanRay r = scan_ray(o, u, cmax);
+  f16v ga = geom[0];
+  for (int g = 0; g < n_groups; g += 2) {
+    const f16v gb = geom[g + 1];
+    group_test(ga, 4 * g, rr, r, o, u, tmin, prev, best, id);
+    ga = geom[g + 2];
+    group_test(gb, 4 * g + 4, rr, r, o, u, tmin, prev, best, id);
   }
 }
 
 __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TraceParams P) {
   const uint32_t lane = threadIdx.x & 63u;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
+  const rr_ptr rr = (rr_ptr)(uintptr_t)P.geom_rr;
 
   // wave-uniform: the chunk being handed out.  A chunk is a run of chunk_paths consecutive paths
   // in pixel-major order (all samples of a pixel, then the next pixel of the row list).
@@ -146,6 +194,8 @@ __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TracePa
     if (__ballot(alive) == 0) break;
 
     // ---- one segment: world.hit + scatter (raytracer.nim:11-16)
+    RTOW_COUNT(3, 1);
+    RTOW_COUNT(4, __popcll(__ballot(alive)));
     if (alive) {
       ++nseg;
       f3 u; float tmin;
@@ -156,7 +206,7 @@ __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TracePa
         float t;
         if (big_candidate(o, u, bs, tmin, bs.index == prev, t)) offer(t, bs.index, best, id);
       }
-      scan_regular(geom, P.n_geom_pad / 4, o, u, tmin, prev, best, id);
+      scan_regular(geom, rr, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id);
 
       if (P.hit_id && first_sample && depth == P.max_depth) P.hit_id[accpix] = id;
 
@@ -210,6 +260,14 @@ void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_ch
   hipLaunchKernelGGL(rtow_resolve_kernel, dim3((n_channels + 255) / 256), dim3(256), 0, stream, accum, rgb,
                      n_channels, spp);
 }
+
+#ifdef RTOW_PROFILE_COUNTERS
+extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
 
 int trace_blocks_per_cu() {
   int nb = 0;

@@ -132,6 +132,39 @@ RTOW_HD bool regular_candidate(float b, float disc, float tmin, bool self, float
   return true;
 }
 
+// ------------------------------------------------------------------ the scan's filter
+// Every sphere is first screened with  n^2 + (2o).c - k >= |o|^2 - margin,  n = c.u - o.u,
+// k = |c|^2 - r^2 (binary64 on the host, rounded once), which is algebraically
+// disc >= -margin.  margin = 2^-19 (|o| + cmax)^2 with cmax = max(|c| + |r|) over the table: about
+// 32 ulps of the largest intermediate, several times the rounding error the two evaluations can
+// accumulate, and a few percent of r^2 for the scenes this renderer is used on.  Spheres that
+// pass get the exact test; the screen is part of the arithmetic contract (the CPU mirror
+// evaluates it with the same operations in the same order).
+constexpr float kFilterMargin = 1.0f / 524288.0f;  // 2^-19
+
+struct FilterRay {
+  float nou;             // -(o.u)
+  float ox2, oy2, oz2;   // 2*o
+  float threshold;       // |o|^2 - margin
+};
+
+RTOW_HD FilterRay filter_ray(f3 o, f3 u, float cmax) {
+  FilterRay f;
+  f.nou = -dot3(o, u);
+  f.ox2 = 2.0f * o.x; f.oy2 = 2.0f * o.y; f.oz2 = 2.0f * o.z;
+  const float oo = dot3(o, o);
+  const float s = sqrtf(oo) + cmax;
+  f.threshold = oo - kFilterMargin * (s * s);
+  return f;
+}
+
+// filter value of one sphere (the kernels evaluate two at a time with packed instructions)
+RTOW_HD float filter_value(float cx, float cy, float cz, float k, f3 u, const FilterRay& f) {
+  float n = fmaf(cx, u.x, f.nou); n = fmaf(cy, u.y, n); n = fmaf(cz, u.z, n);
+  float t = cx * f.ox2; t = fmaf(cy, f.oy2, t); t = fmaf(cz, f.oz2, t);
+  return fmaf(n, n, t) - k;
+}
+
 struct BigSphere {
   double cx, cy, cz, r;
   int32_t index;  // position in the list

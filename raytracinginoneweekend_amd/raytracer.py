@@ -24,8 +24,8 @@ class Renderer:
     host memory again (the benchmark and the multi-GPU driver rely on that).
     """
 
-    def __init__(self, device=0):
-        self._lib = _lib.lib()
+    def __init__(self, device=0, lib=None):
+        self._lib = lib if lib is not None else _lib.lib()
         h = C.c_void_p()
         _lib.check(self._lib.rtow_create(int(device), C.byref(h)))
         self._h = h

@@ -1,0 +1,30 @@
+"""A/B timing of several builds of librtow_hip.so in ONE process, interleaved rounds.
+usage: ab_bench.py [--spp N] [--rounds R] [--workload C2|C3] lib_a.so lib_b.so ..."""
+import argparse, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracinginoneweekend_amd import _lib, raytracer as R
+ap = argparse.ArgumentParser()
+ap.add_argument("--spp", type=int, default=125)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--workload", default="C2")
+ap.add_argument("libs", nargs="+")
+a = ap.parse_args()
+scene = R.randomScene() if a.workload == "C2" else R.randomScene(lambertBelow=0.0, metalBelow=0.5)
+n = len(scene)
+rs = []
+for path in a.libs:
+    r = R.Renderer(0, lib=_lib.load(os.path.abspath(path)))
+    r.setWorld(scene); r.setCamera(R.bookCamera(1.5))
+    r.renderAsync(1200, 800, 8, 50); r.sync()
+    rs.append(r)
+times = [[] for _ in rs]; seg = [0] * len(rs)
+for _ in range(a.rounds):
+    for k, r in enumerate(rs):
+        r.renderAsync(1200, 800, a.spp, 50); r.sync(); st = r.stats()
+        times[k].append(st["trace_ms"]); seg[k] = st["ray_segments"]
+for k, path in enumerate(a.libs):
+    med, mn = statistics.median(times[k]), min(times[k])
+    flop = seg[k] * (18 * n + 65)
+    print(f"{os.path.basename(path):28s} median {med:8.3f} ms  min {mn:8.3f} ms  {seg[k]/med/1e3:8.1f} Mrays/s  "
+          f"{flop/med/1e9/157.3*100:5.2f}% roofline  segs {seg[k]}")
