@@ -4,9 +4,10 @@
 //                      iterative bounce loop and is refilled with a new path the moment its
 //                      path ends, so the sphere scan always runs with full wavefronts.  Work is
 //                      handed out in chunks (a run of samples of one pixel) from a global
-//                      counter.  Radiance is summed per lane in 64-bit fixed point and flushed
-//                      with integer atomics when the lane moves to another pixel, which makes
-//                      the image independent of scheduling, chunking and GPU count.
+//                      counter.  Radiance is summed per lane in 64-bit fixed point; when lanes move
+//                      on to another pixel their sums are combined with a wavefront reduction
+//                      and added to the frame with integer atomics, which makes the image
+//                      independent of scheduling, chunking and GPU count.
 //  rtow_resolve_kernel mean + sqrt gamma + clamp + 8-bit quantisation (raytracer.nim:22-28).
 //
 // The sphere scan (hittables.nim:79-88 over hitrecord.nim:55-63) keeps the ray in VGPRs and
@@ -20,10 +21,21 @@ namespace rtow {
 #ifdef RTOW_PROFILE_COUNTERS
 // debug build only: [0] wave-level group slow-path entries, [1] wave-level candidate evaluations,
 // [2] lane-level candidate evaluations, [3] wave iterations, [4] lane iterations (alive lanes)
-__device__ unsigned long long g_prof[8];
-#define RTOW_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1))) atomicAdd(&g_prof[i], v_); } while (0)
+__device__ unsigned long long g_prof[16];
+// wave-local accumulation (values are wave-uniform), flushed once when the wave retires
+#define RTOW_PROF_DECL unsigned long long prof_[16] = {0}
+#define RTOW_PROF_PARAM , unsigned long long (&prof_)[16]
+#define RTOW_PROF_ARG , prof_
+#define RTOW_COUNT(i, v) do { prof_[i] += (unsigned long long)(v); } while (0)
+#define RTOW_PROF_FLUSH() do { if ((threadIdx.x & 63u) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_prof[i_], prof_[i_]); } while (0)
+#define RTOW_CLOCK() __builtin_amdgcn_s_memtime()
 #else
+#define RTOW_PROF_DECL
+#define RTOW_PROF_PARAM
+#define RTOW_PROF_ARG
 #define RTOW_COUNT(i, v) do { } while (0)
+#define RTOW_PROF_FLUSH() do { } while (0)
+#define RTOW_CLOCK() 0ull
 #endif
 
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -91,7 +103,7 @@ static __device__ __forceinline__ void exact_test(float cx, float cy, float cz, 
 }
 
 static __device__ __forceinline__ void group_test(const f16v grp, int j, rr_ptr rr, const ScanRay& r, f3 o,
-                                                  f3 u, float tmin, int prev, float& best, int& id) {
+                                                  f3 u, float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
   const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, grp.s67, r);
   const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, grp.sef, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
@@ -109,19 +121,49 @@ static __device__ __forceinline__ void group_test(const f16v grp, int j, rr_ptr 
 // n_groups is even and the table holds one more (all-padding) group after the last one, so the
 // loop can always request two groups ahead without a bounds test.
 static __device__ __forceinline__ void scan_regular(geom_ptr geom, rr_ptr rr, int n_groups, float cmax, f3 o,
-                                                    f3 u, float tmin, int prev, float& best, int& id) {
+                                                    f3 u, float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
   const ScanRay r = scan_ray(o, u, cmax);
   f16v ga = geom[0];
   for (int g = 0; g < n_groups; g += 2) {
     const f16v gb = geom[g + 1];
-    group_test(ga, 4 * g, rr, r, o, u, tmin, prev, best, id);
+    group_test(ga, 4 * g, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     ga = geom[g + 2];
-    group_test(gb, 4 * g + 4, rr, r, o, u, tmin, prev, best, id);
+    group_test(gb, 4 * g + 4, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
   }
 }
 
-__global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TraceParams P) {
+static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Per-pixel accumulation across the wavefront.  Lanes with `want` set hold finished partial
+// sums (fixed point) for pixel `accpix`.  Lanes of the same pixel are added up with a wavefront
+// reduction and ONE lane issues the three 64-bit atomics, so a pixel costs a handful of atomics
+// per wave instead of three per lane.  Must be called by all 64 lanes together.
+static __device__ __forceinline__ void wave_flush(unsigned long long* accum, bool want, uint32_t accpix,
+                                                  unsigned long long acc_r, unsigned long long acc_g,
+                                                  unsigned long long acc_b, uint32_t lane) {
+  uint64_t todo = __ballot(want);
+  while (todo != 0) {
+    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+    const uint32_t pix = (uint32_t)__builtin_amdgcn_readlane((int)accpix, (int)leader);
+    const bool mine = want && accpix == pix;
+    const unsigned long long sr = wave_sum(mine ? acc_r : 0ull);
+    const unsigned long long sg = wave_sum(mine ? acc_g : 0ull);
+    const unsigned long long sb = wave_sum(mine ? acc_b : 0ull);
+    if (lane == leader) {
+      atomicAdd(&accum[3ull * pix + 0], sr);
+      atomicAdd(&accum[3ull * pix + 1], sg);
+      atomicAdd(&accum[3ull * pix + 2], sb);
+    }
+    todo &= ~__ballot(mine);
+  }
+}
+
+__global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const TraceParams P) {
   const uint32_t lane = threadIdx.x & 63u;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
   const rr_ptr rr = (rr_ptr)(uintptr_t)P.geom_rr;
@@ -143,8 +185,10 @@ __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TracePa
   uint32_t accpix = 0xffffffffu;
   unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
   uint32_t nseg = 0;
+  RTOW_PROF_DECL;
 
   for (;;) {
+    const unsigned long long t_refill = RTOW_CLOCK();
     // ---- refill idle lanes
     for (;;) {
       const uint64_t need = __ballot(!alive);
@@ -165,19 +209,15 @@ __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TracePa
       const uint32_t avail = e_end - e_next;
       const uint32_t rank = lanes_below(need);
       const uint32_t cnt = (uint32_t)__popcll(need);
-      if (!alive && rank < avail) {
-        const uint32_t e = s_base + e_next + rank;
-        const uint32_t dp = e / (uint32_t)P.spp;
-        const uint32_t sample = e - dp * (uint32_t)P.spp;
-        const uint32_t pix_local = p_base + dp;
-        if (accpix != pix_local) {
-          if (accpix != 0xffffffffu) {
-            atomicAdd(&P.accum[3ull * accpix + 0], acc_r);
-            atomicAdd(&P.accum[3ull * accpix + 1], acc_g);
-            atomicAdd(&P.accum[3ull * accpix + 2], acc_b);
-          }
-          accpix = pix_local; acc_r = acc_g = acc_b = 0;
-        }
+      const bool take = !alive && rank < avail;
+      const uint32_t e = s_base + e_next + (take ? rank : 0u);
+      const uint32_t dp = e / (uint32_t)P.spp;
+      const uint32_t sample = e - dp * (uint32_t)P.spp;
+      const uint32_t pix_local = p_base + dp;
+      // a lane that moves on to another pixel hands its sums over first
+      wave_flush(P.accum, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
+      if (take) {
+        if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
         const uint32_t r = pix_local / (uint32_t)P.W;
         const int ci = (int)(pix_local - r * (uint32_t)P.W);
         const int y = P.rows ? P.rows[r] : (int)r;
@@ -192,28 +232,32 @@ __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TracePa
       e_next += min(cnt, avail);
     }
     if (__ballot(alive) == 0) break;
+    RTOW_COUNT(4, __popcll(__ballot(alive)));
+    const unsigned long long t_seg = RTOW_CLOCK();
 
     // ---- one segment: world.hit + scatter (raytracer.nim:11-16)
-    RTOW_COUNT(3, 1);
-    RTOW_COUNT(4, __popcll(__ballot(alive)));
+    f3 u = {0, 0, 1};
+    float tmin = 0.0f, best = INFINITY;
+    int id = -1;
     if (alive) {
       ++nseg;
-      f3 u; float tmin;
       segment_begin(d, u, tmin);
-      float best = INFINITY; int id = -1;
       for (int k = 0; k < P.n_big; ++k) {
         const BigSphere bs = P.big[k];
         float t;
         if (big_candidate(o, u, bs, tmin, bs.index == prev, t)) offer(t, bs.index, best, id);
       }
-      scan_regular(geom, rr, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id);
-
+    }
+    const unsigned long long t_scan0 = RTOW_CLOCK();
+    if (alive) scan_regular(geom, rr, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    const unsigned long long t_scan1 = RTOW_CLOCK();
+    if (alive) {
       if (P.hit_id && first_sample && depth == P.max_depth) P.hit_id[accpix] = id;
 
-      float rr = 0.0f, rg = 0.0f, rb = 0.0f;
+      float rr_ = 0.0f, rg_ = 0.0f, rb_ = 0.0f;
       bool ended;
       if (id < 0) {
-        shade_sky(u, tr, tg, tb, rr, rg, rb);
+        shade_sky(u, tr, tg, tb, rr_, rg_, rb_);
         ended = true;
       } else {
         const SphereShade sh = P.shade[id];
@@ -225,21 +269,22 @@ __global__ void __launch_bounds__(kTraceThreads) rtow_trace_kernel(const TracePa
         ended = !scattered || depth <= 0;  // absorbed, or depth exhausted: black (raytracer.nim:8-9,16)
       }
       if (ended) {
-        acc_r += to_fix(rr); acc_g += to_fix(rg); acc_b += to_fix(rb);
+        acc_r += to_fix(rr_); acc_g += to_fix(rg_); acc_b += to_fix(rb_);
         alive = false;
       }
     }
+    RTOW_COUNT(3, 1);
+    RTOW_COUNT(5, t_seg - t_refill);           // refill
+    RTOW_COUNT(6, t_scan0 - t_seg);            // normalise + binary64 spheres
+    RTOW_COUNT(7, t_scan1 - t_scan0);          // scan (filter + exact tests)
+    RTOW_COUNT(8, RTOW_CLOCK() - t_scan1);     // shading
+    (void)t_refill; (void)t_seg; (void)t_scan0; (void)t_scan1;
   }
 
-  if (accpix != 0xffffffffu) {
-    atomicAdd(&P.accum[3ull * accpix + 0], acc_r);
-    atomicAdd(&P.accum[3ull * accpix + 1], acc_g);
-    atomicAdd(&P.accum[3ull * accpix + 2], acc_b);
-  }
+  wave_flush(P.accum, accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
+  RTOW_PROF_FLUSH();
   // ray-segment count: wave reduction, one atomic per wave
-  unsigned long long total = nseg;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+  const unsigned long long total = wave_sum(nseg);
   if (lane == 0) atomicAdd(P.seg_counter, total);
 }
 
@@ -264,7 +309,7 @@ void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_ch
 #ifdef RTOW_PROFILE_COUNTERS
 extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -2;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
   return 0;
 }
 #endif

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from raytracinginoneweekend_amd import raytracer as R, _lib
 L = _lib.lib()
 r = R.Renderer(0); r.setWorld(R.randomScene()); r.setCamera(R.bookCamera(1.5))
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 16)()
 L.rtow_debug_counters(buf, 1)
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 r.renderAsync(1200, 800, spp, 50); r.sync(); st = r.stats()
@@ -14,3 +14,5 @@ L.rtow_debug_counters(buf, 0)
 g, cw, cl, wi, li = buf[0], buf[1], buf[2], buf[3], buf[4]
 print(f"segments {st['ray_segments']}  wave iterations {wi}  lane iterations {li}  lane utilisation {li/(64*wi):.4f}")
 print(f"per wave iteration: group slow-path entries {g/wi:.2f} of 121, candidate spheres (wave level) {cw/wi:.2f}, candidate lanes {cl/wi:.2f} (per lane {cl/li:.3f})")
+tot = buf[5] + buf[6] + buf[7] + buf[8]
+print(f"wave-cycle split: refill {buf[5]/tot:.3f}  normalise+big {buf[6]/tot:.3f}  scan {buf[7]/tot:.3f}  shade {buf[8]/tot:.3f}  (cycles per wave iteration {tot/wi:.0f})")
