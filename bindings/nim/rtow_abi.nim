@@ -1,0 +1,23 @@
+## Nim declarations of the C ABI in include/rtow.h (librtow_hip.so).
+## Unverified in the build image (no Nim toolchain there); kept thin on purpose.
+const rtowLib* = "librtow_hip.so"
+
+type
+  RtowCtx* = distinct pointer
+  RtowCamera* {.bycopy.} = object
+    origin*, lowerLeft*, horizontal*, vertical*, u*, v*, w*: array[3, cfloat]
+    lensRadius*: cfloat
+  RtowStats* {.bycopy.} = object
+    raySegments*, paths*: uint64
+    traceMs*, totalMs*: cfloat
+    nSpheres*, nBig*: int32
+
+proc rtow_last_error*(): cstring {.importc, dynlib: rtowLib.}
+proc rtow_create*(device: cint, ctx: ptr RtowCtx): cint {.importc, dynlib: rtowLib.}
+proc rtow_destroy*(ctx: RtowCtx): cint {.importc, dynlib: rtowLib.}
+proc rtow_set_scene*(ctx: RtowCtx, n: cint, cx, cy, cz, radius: ptr cfloat, kind: ptr uint8,
+                     albedoRgb, fuzz, ir: ptr cfloat): cint {.importc, dynlib: rtowLib.}
+proc rtow_set_camera*(ctx: RtowCtx, cam: ptr RtowCamera): cint {.importc, dynlib: rtowLib.}
+proc rtow_render*(ctx: RtowCtx, w, h, spp, maxDepth: cint, seed: uint64, rows: ptr int32, nRows: cint,
+                  rgbOut: ptr uint8, accumOut: ptr uint64, hitIdOut: ptr int32): cint {.importc, dynlib: rtowLib.}
+proc rtow_get_stats*(ctx: RtowCtx, stats: ptr RtowStats): cint {.importc, dynlib: rtowLib.}

@@ -1,0 +1,57 @@
+// Command-line driver: main of raytracer.nim (:113-138) with its constants as defaults.
+//   rtow_raytracer [--width W] [--ratio R] [--spp N] [--depth D] [--scene random|mix|redblue]
+//                  [--half-extent E] [--out file.ppm] [--device K] [--dump-scene]
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+#include "raytracer.hpp"
+
+using namespace rtowhost;
+
+int main(int argc, char** argv) {
+  int width = 1200, spp = 500, depth = 50, device = 0, halfExtent = 11;
+  double ratio = 3.0 / 2.0;
+  std::string out = "/tmp/test_small.ppm", scene = "random";
+  bool dump = false;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto val = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", a.c_str()); std::exit(2); } return argv[++i]; };
+    if (a == "--width") width = std::atoi(val());
+    else if (a == "--ratio") ratio = std::atof(val());
+    else if (a == "--spp") spp = std::atoi(val());
+    else if (a == "--depth") depth = std::atoi(val());
+    else if (a == "--scene") scene = val();
+    else if (a == "--half-extent") halfExtent = std::atoi(val());
+    else if (a == "--out") out = val();
+    else if (a == "--device") device = std::atoi(val());
+    else if (a == "--dump-scene") dump = true;
+    else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+  }
+  try {
+    const Image img{width, (int)(width / ratio)};
+    HittablesList world = scene == "mix" ? mixOfSpheres() : scene == "redblue" ? sceneRedBlue() : randomScene(halfExtent);
+    if (dump) {  // one line per sphere, full precision: lets a test compare the scene with the oracle's
+      for (const Hittable& h : world) {
+        const Sphere& s = h.hSphere;
+        const Color a = s.mat.kind == mkLambertian ? s.mat.mLambertian.albedo : s.mat.kind == mkMetal ? s.mat.mMetal.albedo : color(0, 0, 0);
+        std::printf("%d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (int)s.mat.kind, s.center[0], s.center[1],
+                    s.center[2], s.radius, a[0], a[1], a[2], s.mat.kind == mkMetal ? s.mat.mMetal.fuzz : 0.0,
+                    s.mat.kind == mkDielectric ? s.mat.mDielectric.ir : 0.0);
+      }
+      return 0;
+    }
+    const Camera cam = scene == "random" ? bookCamera(ratio)
+                       : scene == "mix"  ? initCamera(point(3, 3, 2), point(0, 0, -1), vec3(0, 1, 0), 20, ratio, 2.0, std::sqrt(27.0))
+                                         : initCamera(point(0, 0, 0), point(0, 0, -1), vec3(0, 1, 0), 90, ratio, 0.0, 1.0);
+    rtow_stats st{};
+    render(img, out, world, cam, spp, depth, kRenderSeed, device, &st);
+    std::fprintf(stderr, "%dx%d spp %d depth %d, %d spheres: %llu ray segments, trace %.3f ms (%.1f Mrays/s) -> %s\n", img.width,
+                 img.height, spp, depth, world.len(), (unsigned long long)st.ray_segments, st.trace_ms,
+                 st.ray_segments / (st.trace_ms * 1e3), out.c_str());
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

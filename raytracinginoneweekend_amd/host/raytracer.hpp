@@ -1,0 +1,114 @@
+// Driver with the reference's interface (raytracer.nim): render, the scene builders, the PPM
+// writer.  render() keeps the reference's signature; its j/i/s loops (raytracer.nim:36-45) are
+// one call into librtow_hip.so.
+#pragma once
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/rtow.h"
+#include "camera.hpp"
+#include "hittables.hpp"
+
+namespace rtowhost {
+
+constexpr uint64_t kRenderSeed = 0xE7;  // raytracer.nim:135
+
+inline void check(int status, const char* what) {
+  if (status != RTOW_OK) throw std::runtime_error(std::string(what) + ": " + rtow_last_error());
+}
+
+// The P3 container of raytracer.nim:35,28: header, one "r g b" line per pixel, top row first.
+inline void writePPM(const std::string& path, int w, int h, const std::vector<uint8_t>& rgb) {
+  FILE* f = std::fopen(path.c_str(), "w");
+  if (!f) throw std::runtime_error("cannot open " + path);
+  std::fprintf(f, "P3\n%d %d\n255\n", w, h);
+  for (size_t p = 0; p < (size_t)w * (size_t)h; ++p)
+    std::fprintf(f, "%d %d %d\n", rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2]);
+  std::fclose(f);
+}
+
+// render*(img, f, world, camera, samplesPerPixel, maxDepth)  (raytracer.nim:30-46)
+inline std::vector<uint8_t> render(const Image& img, const std::string& f, const HittablesList& world,
+                                   const Camera& camera, int samplesPerPixel, int maxDepth,
+                                   uint64_t seed = kRenderSeed, int device = 0, rtow_stats* stats = nullptr) {
+  rtow_ctx* ctx = nullptr;
+  check(rtow_create(device, &ctx), "rtow_create");
+  std::vector<uint8_t> rgb((size_t)img.width * (size_t)img.height * 3);
+  try {
+    const HittablesList::Flat s = world.flatten();
+    check(rtow_set_scene(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
+                         s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene");
+    const rtow_camera cam = camera.flat();
+    check(rtow_set_camera(ctx, &cam), "rtow_set_camera");
+    check(rtow_render(ctx, img.width, img.height, samplesPerPixel, maxDepth, seed, nullptr, img.height,
+                      rgb.data(), nullptr, nullptr), "rtow_render");
+    if (stats) check(rtow_get_stats(ctx, stats), "rtow_get_stats");
+  } catch (...) {
+    rtow_destroy(ctx);
+    throw;
+  }
+  rtow_destroy(ctx);
+  if (!f.empty()) writePPM(f, img.width, img.height, rgb);
+  return rgb;
+}
+
+inline HittablesList sceneRedBlue() {  // raytracer.nim:48-59
+  HittablesList result = initHittables(0);
+  const double R = std::cos(3.14159265358979323846 / 4.0);
+  result.add(Sphere{point(-R, 0, -1), R, initMaterial(initLambertian(color(0, 0, 1)))});
+  result.add(Sphere{point(R, 0, -1), R, initMaterial(initLambertian(color(1, 0, 0)))});
+  return result;
+}
+
+inline HittablesList mixOfSpheres() {  // raytracer.nim:61-73 (fourth sphere: negative radius)
+  HittablesList result = initHittables(0);
+  const Material matLeft = initMaterial(initDielectric(1.5));
+  result.add(Sphere{point(0, -100.5, -1), 100, initMaterial(initLambertian(color(0.8, 0.8, 0.0)))});
+  result.add(Sphere{point(0, 0, -1), 0.5, initMaterial(initLambertian(color(0.1, 0.2, 0.5)))});
+  result.add(Sphere{point(-1.0, 0, -1), 0.5, matLeft});
+  result.add(Sphere{point(-1.0, 0, -1), -0.4, matLeft});
+  result.add(Sphere{point(1.0, 0, -1), 0.5, initMaterial(initMetal(color(0.8, 0.6, 0.2), 1.0))});
+  return result;
+}
+
+// randomScene (raytracer.nim:75-111); halfExtent 11 and thresholds 0.8 / 0.95 are the reference's
+inline HittablesList randomScene(int halfExtent = 11, double lambertBelow = 0.8, double metalBelow = 0.95,
+                                 NimRand* rng = nullptr) {
+  NimRand local;
+  NimRand& g = rng ? *rng : local;
+  HittablesList result = initHittables(0);
+  result.add(Sphere{point(0, -1000, 0), 1000, initMaterial(initLambertian(color(0.5, 0.5, 0.5)))});
+  for (int a = -halfExtent; a < halfExtent; ++a)
+    for (int b = -halfExtent; b < halfExtent; ++b) {
+      const double chooseMat = g.rand(1.0);
+      const double cx = (double)a + 0.9 * g.rand(1.0);
+      const double cz = (double)b + 0.9 * g.rand(1.0);
+      const Point center = point(cx, 0.2, cz);
+      if (length(center - point(4, 0.2, 0)) > 0.9) {
+        Material m;
+        if (chooseMat < lambertBelow) {
+          const Vec3 first = randomVec(g);
+          const Vec3 second = randomVec(g);
+          m = initMaterial(initLambertian(first * second));
+        } else if (chooseMat < metalBelow) {
+          const Vec3 albedo = randomVec(g, 0.5, 1.0);
+          const double fuzz = g.rand(0.0, 0.5);
+          m = initMaterial(initMetal(albedo, fuzz));
+        } else {
+          m = initMaterial(initDielectric(1.5));
+        }
+        result.add(Sphere{center, 0.2, m});
+      }
+    }
+  result.add(Sphere{point(0, 1, 0), 1.0, initMaterial(initDielectric(1.5))});
+  result.add(Sphere{point(-4, 1, 0), 1.0, initMaterial(initLambertian(color(0.4, 0.2, 0.1)))});
+  result.add(Sphere{point(4, 1, 0), 1.0, initMaterial(initMetal(color(0.7, 0.6, 0.5), 0.0))});
+  return result;
+}
+
+inline Camera bookCamera(double aspectRatio) {  // raytracer.nim:125-132
+  return initCamera(point(13, 2, 3), point(0, 0, 0), vec3(0, 1, 0), 20, aspectRatio, 0.1, 10.0);
+}
+
+}  // namespace rtowhost
