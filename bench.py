@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks "
+                         "(ranks share devices, rows are gathered through host memory); not a valid benchmark")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,17 +90,23 @@ def main():
     seed = 0xE7
 
     dist = torch = None
+    device = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            device = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(device)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
 
     from raytracinginoneweekend_amd import multigpu, raytracer as R
 
     world_scene = R.randomScene(halfExtent=half_extent, lambertBelow=lam, metalBelow=met)
     n_spheres = len(world_scene)
-    r = R.Renderer(local_rank)
+    r = R.Renderer(device)
     r.setWorld(world_scene)
     r.setCamera(R.bookCamera(width / height))
 
@@ -106,7 +115,7 @@ def main():
     n_rows = height if rows is None else len(rows)
     local_rgb = None
     if world > 1:
-        local_rgb = torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        local_rgb = torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{device}")
 
     def sync_all():
         if world > 1:
@@ -120,7 +129,7 @@ def main():
         r.sync()
         st = r.stats()
         if world > 1:
-            multigpu.gather_image(local_rgb, height, width, world, rank, tile)
+            multigpu.gather_image(local_rgb if args.backend == "nccl" else local_rgb.cpu(), height, width, world, rank, tile)
         return st
 
     for _ in range(args.warmup):
@@ -142,10 +151,11 @@ def main():
 
     seg_per_step_local = segments / max(1, args.steps)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        red_dev = f"cuda:{device}" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([segments], dtype=torch.int64, device=f"cuda:{local_rank}")
+        s = torch.tensor([segments], dtype=torch.int64, device=red_dev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         segments = int(s.item())
 
@@ -171,7 +181,9 @@ def main():
                 "workload": f"{args.workload}: book-1 random-spheres scene, {width}x{height}, spp {spp}, depth {depth}, "
                             f"{n_spheres} spheres in a linear list, seed 0xE7",
                 "width": width, "height": height, "spp": spp, "max_depth": depth, "n_spheres": n_spheres,
-                "parallelism": "single GPU" if world == 1 else f"interleaved {tile}-row tiles over {world} GPUs + RCCL all_gather of 8-bit rows",
+                "parallelism": "single GPU" if world == 1 else (
+                    f"interleaved {tile}-row tiles over {world} GPUs + RCCL all_gather of 8-bit rows" if args.backend == "nccl"
+                    else f"REHEARSAL: {world} gloo ranks sharing devices (not a benchmark)"),
                 "paths_per_step": paths,
                 "segments_per_step": segments // max(1, args.steps),
                 "mean_segments_per_path": segments / max(1, args.steps) / paths,

@@ -42,7 +42,8 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 // constant address space: wave-uniform loads from it become s_load_dwordx16 into SGPRs
 typedef const f16v __attribute__((address_space(4)))* geom_ptr;
-typedef const float __attribute__((address_space(4)))* rr_ptr;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const f4v __attribute__((address_space(4)))* rr_ptr;  // r^2 of the four spheres of a group
 
 // per-ray operands of the packed filter, every component duplicated into both halves of a pair
 struct ScanRay {
@@ -99,7 +100,8 @@ static __device__ __forceinline__ void exact_test(float cx, float cy, float cz, 
   float m = fmaf(-ocx, ocx, rr); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
   const float disc = fmaf(b, b, m);
   float t;
-  if (disc >= 0.0f && regular_candidate(b, disc, tmin, j == prev, t)) offer(t, j, best, id);
+  const bool ok = regular_candidate(b, disc, tmin, j == prev, t);
+  offer(disc >= 0.0f && ok, t, j, best, id);
 }
 
 static __device__ __forceinline__ void group_test(const f16v grp, int j, rr_ptr rr, const ScanRay& r, f3 o,
@@ -111,10 +113,11 @@ static __device__ __forceinline__ void group_test(const f16v grp, int j, rr_ptr 
     RTOW_COUNT(0, 1);
     RTOW_COUNT(1, (__ballot(f0.x >= r.threshold) != 0) + (__ballot(f0.y >= r.threshold) != 0) + (__ballot(f1.x >= r.threshold) != 0) + (__ballot(f1.y >= r.threshold) != 0));
     RTOW_COUNT(2, __popcll(__ballot(f0.x >= r.threshold)) + __popcll(__ballot(f0.y >= r.threshold)) + __popcll(__ballot(f1.x >= r.threshold)) + __popcll(__ballot(f1.y >= r.threshold)));
-    if (f0.x >= r.threshold) exact_test(grp.s0, grp.s2, grp.s4, rr[j], j, o, u, tmin, prev, best, id);
-    if (f0.y >= r.threshold) exact_test(grp.s1, grp.s3, grp.s5, rr[j + 1], j + 1, o, u, tmin, prev, best, id);
-    if (f1.x >= r.threshold) exact_test(grp.s8, grp.sa, grp.sc, rr[j + 2], j + 2, o, u, tmin, prev, best, id);
-    if (f1.y >= r.threshold) exact_test(grp.s9, grp.sb, grp.sd, rr[j + 3], j + 3, o, u, tmin, prev, best, id);
+    const f4v r4 = rr[j >> 2];
+    if (f0.x >= r.threshold) exact_test(grp.s0, grp.s2, grp.s4, r4.x, j, o, u, tmin, prev, best, id);
+    if (f0.y >= r.threshold) exact_test(grp.s1, grp.s3, grp.s5, r4.y, j + 1, o, u, tmin, prev, best, id);
+    if (f1.x >= r.threshold) exact_test(grp.s8, grp.sa, grp.sc, r4.z, j + 2, o, u, tmin, prev, best, id);
+    if (f1.y >= r.threshold) exact_test(grp.s9, grp.sb, grp.sd, r4.w, j + 3, o, u, tmin, prev, best, id);
   }
 }
 
@@ -172,6 +175,7 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
   // in pixel-major order (all samples of a pixel, then the next pixel of the row list).
   uint32_t e_next = 0, e_end = 0;     // offsets inside the chunk
   uint32_t p_base = 0, s_base = 0;    // pixel and sample of the chunk's first path
+  uint32_t r_base = 0, i_base = 0;    // row (in the row list) and column of that pixel
   bool exhausted = false;
 
   // per lane: the path in flight
@@ -203,6 +207,8 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
         const unsigned long long left = P.total_paths - first;
         p_base = (uint32_t)(first / (uint32_t)P.spp);
         s_base = (uint32_t)(first - (unsigned long long)p_base * (uint32_t)P.spp);
+        r_base = p_base / (uint32_t)P.W;
+        i_base = p_base - r_base * (uint32_t)P.W;
         e_next = 0;
         e_end = left < P.chunk_paths ? (uint32_t)left : P.chunk_paths;
       }
@@ -210,16 +216,25 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       const uint32_t rank = lanes_below(need);
       const uint32_t cnt = (uint32_t)__popcll(need);
       const bool take = !alive && rank < avail;
+      // (pixel, sample) of the path this lane would take: e counts samples from the first sample
+      // of the chunk's first pixel.  With spp >= chunk_paths it overflows spp at most once.
       const uint32_t e = s_base + e_next + (take ? rank : 0u);
-      const uint32_t dp = e / (uint32_t)P.spp;
-      const uint32_t sample = e - dp * (uint32_t)P.spp;
+      uint32_t dp, sample;
+      if ((uint32_t)P.spp >= P.chunk_paths) {
+        dp = e >= (uint32_t)P.spp ? 1u : 0u;
+        sample = e - (dp ? (uint32_t)P.spp : 0u);
+      } else {
+        dp = e / (uint32_t)P.spp;
+        sample = e - dp * (uint32_t)P.spp;
+      }
       const uint32_t pix_local = p_base + dp;
       // a lane that moves on to another pixel hands its sums over first
       wave_flush(P.accum, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
       if (take) {
         if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
-        const uint32_t r = pix_local / (uint32_t)P.W;
-        const int ci = (int)(pix_local - r * (uint32_t)P.W);
+        uint32_t r = r_base, col = i_base + dp;
+        while (col >= (uint32_t)P.W) { col -= (uint32_t)P.W; ++r; }
+        const int ci = (int)col;
         const int y = P.rows ? P.rows[r] : (int)r;
         g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample);
         camera_ray(P.cam, ci, P.H - 1 - y, P.W, P.H, g, o, d);
@@ -245,7 +260,8 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       for (int k = 0; k < P.n_big; ++k) {
         const BigSphere bs = P.big[k];
         float t;
-        if (big_candidate(o, u, bs, tmin, bs.index == prev, t)) offer(t, bs.index, best, id);
+        const bool ok = big_candidate(o, u, bs, tmin, bs.index == prev, t);
+        offer(ok, t, bs.index, best, id);
       }
     }
     const unsigned long long t_scan0 = RTOW_CLOCK();

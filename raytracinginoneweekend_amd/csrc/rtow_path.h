@@ -119,17 +119,13 @@ RTOW_HD void segment_begin(f3 d, f3& u, float& tmin) {
 // >= tmin (hitrecord.nim:66-71).  self: the ray starts on this sphere, so the near root is 0 by
 // construction and only t = -2b is offered.
 RTOW_HD bool regular_candidate(float b, float disc, float tmin, bool self, float& t) {
-  if (self) {
-    t = -2.0f * b;
-    return !(t < tmin);
-  }
+  // written with selects instead of branches: few lanes ever get here and the GPU runs both
+  // sides of a branch anyway
   const float s = sqrtf(disc);
-  t = -b - s;
-  if (t < tmin) {
-    t = -b + s;
-    if (t < tmin) return false;
-  }
-  return true;
+  const float t_near = -b - s, t_far = -b + s;
+  t = t_near < tmin ? t_far : t_near;
+  t = self ? -2.0f * b : t;
+  return !(t < tmin);
 }
 
 // ------------------------------------------------------------------ the scan's filter
@@ -195,8 +191,10 @@ RTOW_HD bool big_candidate(f3 o, f3 u, const BigSphere& s, float tmin, bool self
 
 // closest-so-far update: smaller t wins, equal t goes to the later list index
 // (hittables.nim:84-88 accepts root <= closestSoFar while scanning in list order)
-RTOW_HD void offer(float t, int j, float& best, int& id) {
-  if (t < best || (t == best && j > id)) { best = t; id = j; }
+RTOW_HD void offer(bool valid, float t, int j, float& best, int& id) {
+  const bool better = valid && (t < best || (t == best && j > id));
+  best = better ? t : best;
+  id = better ? j : id;
 }
 
 // ------------------------------------------------------------------ shading

@@ -10,7 +10,8 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--workload", default="C2")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
-scene = R.randomScene() if a.workload == "C2" else R.randomScene(lambertBelow=0.0, metalBelow=0.5)
+scene = {"C2": lambda: R.randomScene(), "C3": lambda: R.randomScene(lambertBelow=0.0, metalBelow=0.5),
+         "C5": lambda: R.randomScene(halfExtent=50)}[a.workload]()
 n = len(scene)
 rs = []
 for path in a.libs:
