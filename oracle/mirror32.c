@@ -14,9 +14,10 @@
  *     0.001f*|d| in distance units;
  *   - rayColor's recursion (raytracer.nim:5-20) becomes a loop that carries the product of
  *     attenuations (throughput) outside-in;
- *   - spheres with |radius| >= 100 (the 1000-unit ground sphere, raytracer.nim:79) are
- *     intersected in binary64 from the binary32 ray, because |oc|^2 - r^2 cancels
- *     catastrophically in binary32; all other spheres use binary32 only;
+ *   - spheres with |radius| >= 100 (the 1000-unit ground sphere, raytracer.nim:79) get oc, oc.u,
+ *     |oc|^2 - r^2 and the discriminant in binary64 from the binary32 ray, because |oc|^2 - r^2
+ *     cancels catastrophically in binary32; their roots are then taken in binary32 as
+ *     q = -(b + sign(b) sqrt(disc)), {q, c/q}; all other spheres use binary32 only;
  *   - every binary32 sphere is first screened by a cheaper evaluation of its discriminant,
  *     n^2 + (2o).c - k >= |o|^2 - 2^-19 (|o| + cmax)^2 with n = c.u - o.u and k = |c|^2 - r^2,
  *     and only spheres that pass get the exact test below (the screen is there because the GPU
@@ -151,25 +152,27 @@ static int closest_hit(const sph32* w, int n, float cmax, f3 o, f3 u, float tmin
         }
       }
     } else {
+      /* binary64 up to the discriminant, then binary32 roots in the cancellation-free form
+       * q = -(b + sign(b) sqrt(disc)), {q, c/q} */
       const double ux = u.x, uy = u.y, uz = u.z;
       const double ocx = (double)o.x - (double)w[j].cx, ocy = (double)o.y - (double)w[j].cy,
                    ocz = (double)o.z - (double)w[j].cz;
-      const double a = ux * ux + uy * uy + uz * uz;
-      const double hb = ocx * ux + ocy * uy + ocz * uz;
-      const double c = ocx * ocx + ocy * ocy + ocz * ocz - (double)w[j].r * (double)w[j].r;
-      const double disc = hb * hb - a * c;
+      const double rr = (double)w[j].r * (double)w[j].r;
+      const double hb = fma(ocz, uz, fma(ocy, uy, ocx * ux));
+      const double c = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -rr)));
+      const double disc = fma(hb, hb, -c);
       if (!(disc >= 0.0)) continue;
+      const float bf = (float)hb, cf = (float)c;
       if (j == prev) {
-        t = (float)(-2.0 * hb / a);
-        if (t < tmin) continue;
+        t = -2.0f * bf;
       } else {
-        const double sq = sqrt(disc);
-        t = (float)((-hb - sq) / a);
-        if (t < tmin) {
-          t = (float)((-hb + sq) / a);
-          if (t < tmin) continue;
-        }
+        const float sq = sqrtf((float)disc);
+        const float q = bf < 0.0f ? sq - bf : -bf - sq;
+        const float other = cf / q;
+        const float t_near = fminf(q, other), t_far = fmaxf(q, other);
+        t = t_near < tmin ? t_far : t_near;
       }
+      if (t < tmin) continue;
     }
     if (t <= best) { best = t; id = j; }
   }

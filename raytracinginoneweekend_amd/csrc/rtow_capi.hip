@@ -167,7 +167,7 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     }
     if (is_big) {
       rtow::BigSphere b;
-      b.cx = cx[j]; b.cy = cy[j]; b.cz = cz[j]; b.r = r; b.index = j; b.pad_ = 0;
+      b.cx = cx[j]; b.cy = cy[j]; b.cz = cz[j]; b.r = r; b.rr = (double)r * (double)r; b.index = j; b.pad_ = 0;
       big.push_back(b);
     }
     rtow::SphereShade& s = shade[j];

@@ -163,30 +163,30 @@ RTOW_HD float filter_value(float cx, float cy, float cz, float k, f3 u, const Fi
 
 struct BigSphere {
   double cx, cy, cz, r;
+  double rr;      // r*r
   int32_t index;  // position in the list
   int32_t pad_;
 };
 
-// The same test in binary64 for |r| >= kBigRadius, from the binary32 ray.
+// Spheres with |r| >= kBigRadius: |oc|^2 - r^2 cancels catastrophically in binary32 (the ground
+// sphere has r = 1000 and rays start within a few units of its surface), so oc, b = oc.u,
+// c = |oc|^2 - r^2 and the discriminant are evaluated in binary64 from the binary32 ray.  The
+// roots are then taken in binary32 in the cancellation-free form  q = -(b + sign(b) sqrt(disc)),
+// {q, c/q}  (a = |u|^2 is 1 to rounding, as for every other sphere).
 RTOW_HD bool big_candidate(f3 o, f3 u, const BigSphere& s, float tmin, bool self, float& t) {
   const double ux = u.x, uy = u.y, uz = u.z;
   const double ocx = (double)o.x - s.cx, ocy = (double)o.y - s.cy, ocz = (double)o.z - s.cz;
-  const double a = ux * ux + uy * uy + uz * uz;
-  const double hb = ocx * ux + ocy * uy + ocz * uz;
-  const double c = ocx * ocx + ocy * ocy + ocz * ocz - s.r * s.r;
-  const double disc = hb * hb - a * c;
-  if (!(disc >= 0.0)) return false;
-  if (self) {
-    t = (float)(-2.0 * hb / a);
-    return !(t < tmin);
-  }
-  const double sq = sqrt(disc);
-  t = (float)((-hb - sq) / a);
-  if (t < tmin) {
-    t = (float)((-hb + sq) / a);
-    if (t < tmin) return false;
-  }
-  return true;
+  const double hb = fma(ocz, uz, fma(ocy, uy, ocx * ux));
+  const double c = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -s.rr)));
+  const double disc = fma(hb, hb, -c);
+  const float bf = (float)hb, cf = (float)c;
+  const float sq = sqrtf((float)disc);
+  const float q = bf < 0.0f ? sq - bf : -bf - sq;
+  const float other = cf / q;
+  const float t_near = fminf(q, other), t_far = fmaxf(q, other);
+  t = t_near < tmin ? t_far : t_near;
+  t = self ? -2.0f * bf : t;
+  return disc >= 0.0 && !(t < tmin);
 }
 
 // closest-so-far update: smaller t wins, equal t goes to the later list index
