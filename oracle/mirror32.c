@@ -19,7 +19,7 @@
  *     cancels catastrophically in binary32; their roots are then taken in binary32 as
  *     q = -(b + sign(b) sqrt(disc)), {q, c/q}; all other spheres use binary32 only;
  *   - every binary32 sphere is first screened by a cheaper evaluation of its discriminant,
- *     n^2 + (2o).c - k >= |o|^2 - 2^-19 (|o| + cmax)^2 with n = c.u - o.u and k = |c|^2 - r^2,
+ *     n^2 + ((2o).c - k) >= |o|^2 - 2^-19 (|o| + cmax)^2 with n = c.u - o.u and k = |c|^2 - r^2,
  *     and only spheres that pass get the exact test below (the screen is there because the GPU
  *     evaluates it for two spheres per packed instruction; its margin is several times the
  *     rounding error of both evaluations, so in practice it only removes non-candidates);
@@ -133,8 +133,8 @@ static int closest_hit(const sph32* w, int n, float cmax, f3 o, f3 u, float tmin
     float t;
     if (!w[j].big) {
       float fn = fmaf(w[j].cx, u.x, nou); fn = fmaf(w[j].cy, u.y, fn); fn = fmaf(w[j].cz, u.z, fn);
-      float ft = w[j].cx * ox2; ft = fmaf(w[j].cy, oy2, ft); ft = fmaf(w[j].cz, oz2, ft);
-      if (!(fmaf(fn, fn, ft) - w[j].k >= threshold)) continue;
+      float ft = fmaf(w[j].cx, ox2, -w[j].k); ft = fmaf(w[j].cy, oy2, ft); ft = fmaf(w[j].cz, oz2, ft);
+      if (!(fmaf(fn, fn, ft) >= threshold)) continue;
       const float ocx = o.x - w[j].cx, ocy = o.y - w[j].cy, ocz = o.z - w[j].cz;
       float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
       float m = fmaf(-ocx, ocx, w[j].r2); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);

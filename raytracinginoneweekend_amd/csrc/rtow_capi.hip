@@ -60,7 +60,7 @@ struct rtow_ctx {
   // scene
   bool have_scene = false, have_camera = false;
   int n_spheres = 0, n_geom_pad = 0, n_big = 0;
-  DevBuf geom, geom_rr, big, shade;
+  DevBuf geom, geom_rr, geom_nk, big, shade;
   float cmax = 0.0f;
   rtow::CameraParams cam;
 
@@ -107,7 +107,6 @@ int rtow_create(int device, rtow_ctx** out) {
     return fail(RTOW_ERR_DEVICE, "rtow_create: %s", hipGetErrorString(e));
   }
   c->n_cu = prop.multiProcessorCount;
-  c->blocks_per_cu = rtow::trace_blocks_per_cu();
   *out = c;
   return RTOW_OK;
 }
@@ -116,7 +115,7 @@ int rtow_destroy(rtow_ctx* c) {
   if (!c) return RTOW_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->geom.release(); c->geom_rr.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
+  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   if (c->host_counters) (void)hipHostFree(c->host_counters);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -152,7 +151,7 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   std::vector<rtow::SphereShade> shade((size_t)(n > 0 ? n : 1));
   std::vector<rtow::BigSphere> big;
   for (int j = 0; j < n_alloc; ++j) geom_at(j, 3) = INFINITY;
-  std::vector<float> rr((size_t)n_alloc, 0.0f);
+  std::vector<float> rr((size_t)n_alloc, 0.0f), nk((size_t)n_alloc, -INFINITY);
   float cmax = 0.0f;
   for (int j = 0; j < n; ++j) {
     const float r = radius[j];
@@ -162,6 +161,7 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
       const double c2 = (double)cx[j] * cx[j] + (double)cy[j] * cy[j] + (double)cz[j] * cz[j];
       geom_at(j, 3) = (float)(c2 - (double)r * r);
       rr[j] = r * r;
+      nk[j] = -geom_at(j, 3);
       const float reach = (float)std::sqrt(c2) + std::fabs(r);
       if (reach > cmax) cmax = reach;
     }
@@ -177,15 +177,18 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   }
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float) * rr.size()));
+  HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
   HIP_TRY(c->big.reserve(sizeof(rtow::BigSphere) * (big.empty() ? 1 : big.size())));
   HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float) * geom.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->geom_rr.p, rr.data(), sizeof(float) * rr.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->geom_nk.p, nk.data(), sizeof(float) * nk.size(), hipMemcpyHostToDevice));
   c->cmax = cmax;
   HIP_TRY(hipMemcpy(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice));
   if (!big.empty())
     HIP_TRY(hipMemcpy(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice));
   c->n_spheres = n; c->n_geom_pad = n_pad; c->n_big = (int)big.size();
+  c->blocks_per_cu = rtow::trace_blocks_per_cu(n_pad);
   c->have_scene = true;
   return RTOW_OK;
 }
@@ -234,7 +237,7 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
 
   rtow::TraceParams p;
   p.cam = c->cam;
-  p.geom = (const float*)c->geom.p; p.geom_rr = (const float*)c->geom_rr.p; p.n_geom_pad = c->n_geom_pad;
+  p.geom = (const float*)c->geom.p; p.geom_rr = (const float*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
   p.cmax = c->cmax;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;

@@ -6,11 +6,13 @@
 namespace rtow {
 
 constexpr int kTraceThreads = 256;   // 4 wavefronts per workgroup
-constexpr int kGeomPad = 8;          // the regular sphere table is padded to a multiple of this
+constexpr int kGeomPad = 8;
+constexpr int kMaxSpheresKInLds = 4096;  // up to this many table entries the filter reads -k from LDS (16 KB)          // the regular sphere table is padded to a multiple of this
 
 struct TraceParams {
   CameraParams cam;
   const float* geom;         // n_geom_pad/4 groups of 16 floats (layout: scan_regular), list order
+  const float* geom_nk;      // -k per list entry (n_geom_pad + 4 values): copied to LDS by each workgroup
   const float* geom_rr;      // r^2 per list entry (n_geom_pad values), for the exact test
   int n_geom_pad;
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin
@@ -32,6 +34,6 @@ struct TraceParams {
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);
-int trace_blocks_per_cu();
+int trace_blocks_per_cu(int n_geom_pad);
 
 }  // namespace rtow

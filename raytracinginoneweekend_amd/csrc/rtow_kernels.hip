@@ -82,15 +82,15 @@ static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
 // One s_load_dwordx16 brings a group into SGPRs, two groups ahead of its use.  Spheres handled
 // elsewhere and the padding carry k = +inf, so they never pass.  r^2 for the exact test comes from
 // a separate array, fetched only when needed.
-static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, const f2v cz, const f2v k,
+static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, const f2v cz, const f2v nk,
                                                   const ScanRay& r) {
   f2v n = __builtin_elementwise_fma(cx, r.ux, r.nou);
   n = __builtin_elementwise_fma(cy, r.uy, n);
   n = __builtin_elementwise_fma(cz, r.uz, n);
-  f2v t = cx * r.ox2;
+  f2v t = __builtin_elementwise_fma(cx, r.ox2, nk);   // nk = -k, a VGPR pair (see K_LDS)
   t = __builtin_elementwise_fma(cy, r.oy2, t);
   t = __builtin_elementwise_fma(cz, r.oz2, t);
-  return __builtin_elementwise_fma(n, n, t) - k;
+  return __builtin_elementwise_fma(n, n, t);
 }
 
 static __device__ __forceinline__ void exact_test(float cx, float cy, float cz, float rr, int j, f3 o, f3 u,
@@ -104,13 +104,13 @@ static __device__ __forceinline__ void exact_test(float cx, float cy, float cz, 
   offer(disc >= 0.0f && ok, t, j, best, id);
 }
 
-static __device__ __forceinline__ void group_test(const f16v grp, int j, rr_ptr rr, const ScanRay& r, f3 o,
-                                                  f3 u, float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
-  const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, grp.s67, r);
-  const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, grp.sef, r);
+static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, int j, rr_ptr rr, const ScanRay& r,
+                                                  f3 o, f3 u, float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
+  const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, nk.xy, r);
+  const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
   if (mx >= r.threshold) {
-    RTOW_COUNT(0, 1);
+    RTOW_COUNT(0, 1);  // lane 0 only sees its own entries; counters 9..11 are wave level
     RTOW_COUNT(1, (__ballot(f0.x >= r.threshold) != 0) + (__ballot(f0.y >= r.threshold) != 0) + (__ballot(f1.x >= r.threshold) != 0) + (__ballot(f1.y >= r.threshold) != 0));
     RTOW_COUNT(2, __popcll(__ballot(f0.x >= r.threshold)) + __popcll(__ballot(f0.y >= r.threshold)) + __popcll(__ballot(f1.x >= r.threshold)) + __popcll(__ballot(f1.y >= r.threshold)));
     const f4v r4 = rr[j >> 2];
@@ -123,16 +123,28 @@ static __device__ __forceinline__ void group_test(const f16v grp, int j, rr_ptr 
 
 // n_groups is even and the table holds one more (all-padding) group after the last one, so the
 // loop can always request two groups ahead without a bounds test.
-static __device__ __forceinline__ void scan_regular(geom_ptr geom, rr_ptr rr, int n_groups, float cmax, f3 o,
-                                                    f3 u, float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
+//
+// K_LDS: -k of every sphere sits in LDS (copied once per workgroup) and reaches the filter as a
+// VGPR pair through a broadcast ds_read_b128 issued one group ahead.  That lets the second chain
+// start as fma(cx, 2o.x, -k): a VALU instruction can read only one SGPR operand, so with k in an
+// SGPR the subtraction would cost a packed instruction of its own.  Tables too large for LDS use
+// the SGPR copy of k (moved to VGPRs first; same arithmetic, two more instructions per group).
+template <bool K_LDS>
+static __device__ __forceinline__ void scan_regular(geom_ptr geom, rr_ptr rr, const f4v* nk_lds, int n_groups,
+                                                    float cmax, f3 o, f3 u, float tmin, int prev, float& best,
+                                                    int& id RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
   const ScanRay r = scan_ray(o, u, cmax);
   f16v ga = geom[0];
+  f4v ka = K_LDS ? nk_lds[0] : f4v{0, 0, 0, 0};
   for (int g = 0; g < n_groups; g += 2) {
     const f16v gb = geom[g + 1];
-    group_test(ga, 4 * g, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    f4v kb;
+    if (K_LDS) kb = nk_lds[g + 1]; else ka = f4v{-ga.s6, -ga.s7, -ga.se, -ga.sf};
+    group_test(ga, ka, 4 * g, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     ga = geom[g + 2];
-    group_test(gb, 4 * g + 4, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    if (K_LDS) ka = nk_lds[g + 2]; else kb = f4v{-gb.s6, -gb.s7, -gb.se, -gb.sf};
+    group_test(gb, kb, 4 * g + 4, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
   }
 }
 
@@ -166,10 +178,17 @@ static __device__ __forceinline__ void wave_flush(unsigned long long* accum, boo
   }
 }
 
+template <bool K_LDS>
 __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const TraceParams P) {
+  extern __shared__ f4v nk_lds[];   // K_LDS: -k per sphere, (n_geom_pad + 4) floats
   const uint32_t lane = threadIdx.x & 63u;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
   const rr_ptr rr = (rr_ptr)(uintptr_t)P.geom_rr;
+  if (K_LDS) {
+    const int n4 = P.n_geom_pad / 4 + 1;
+    for (int i = threadIdx.x; i < n4; i += kTraceThreads) nk_lds[i] = ((const f4v*)P.geom_nk)[i];
+    __syncthreads();
+  }
 
   // wave-uniform: the chunk being handed out.  A chunk is a run of chunk_paths consecutive paths
   // in pixel-major order (all samples of a pixel, then the next pixel of the row list).
@@ -265,7 +284,7 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       }
     }
     const unsigned long long t_scan0 = RTOW_CLOCK();
-    if (alive) scan_regular(geom, rr, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    if (alive) scan_regular<K_LDS>(geom, rr, nk_lds, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     const unsigned long long t_scan1 = RTOW_CLOCK();
     if (alive) {
       if (P.hit_id && first_sample && depth == P.max_depth) P.hit_id[accpix] = id;
@@ -311,8 +330,14 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
   if (i < n_channels) rgb[i] = (uint8_t)quantise_fix(accum[i], spp);
 }
 
+static size_t k_lds_bytes(int n_geom_pad) { return sizeof(float) * (size_t)(n_geom_pad + 4); }
+
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(rtow_trace_kernel, dim3(grid_blocks), dim3(kTraceThreads), 0, stream, p);
+  if (p.n_geom_pad <= kMaxSpheresKInLds)
+    hipLaunchKernelGGL(rtow_trace_kernel<true>, dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
+                       stream, p);
+  else
+    hipLaunchKernelGGL(rtow_trace_kernel<false>, dim3(grid_blocks), dim3(kTraceThreads), 0, stream, p);
 }
 
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
@@ -330,10 +355,14 @@ extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
 }
 #endif
 
-int trace_blocks_per_cu() {
+int trace_blocks_per_cu(int n_geom_pad) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel, kTraceThreads, 0) != hipSuccess || nb < 1)
-    nb = 1;
+  hipError_t e;
+  if (n_geom_pad <= kMaxSpheresKInLds)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true>, kTraceThreads, k_lds_bytes(n_geom_pad));
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false>, kTraceThreads, 0);
+  if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
 

@@ -157,8 +157,8 @@ RTOW_HD FilterRay filter_ray(f3 o, f3 u, float cmax) {
 // filter value of one sphere (the kernels evaluate two at a time with packed instructions)
 RTOW_HD float filter_value(float cx, float cy, float cz, float k, f3 u, const FilterRay& f) {
   float n = fmaf(cx, u.x, f.nou); n = fmaf(cy, u.y, n); n = fmaf(cz, u.z, n);
-  float t = cx * f.ox2; t = fmaf(cy, f.oy2, t); t = fmaf(cz, f.oz2, t);
-  return fmaf(n, n, t) - k;
+  float t = fmaf(cx, f.ox2, -k); t = fmaf(cy, f.oy2, t); t = fmaf(cz, f.oz2, t);
+  return fmaf(n, n, t);
 }
 
 struct BigSphere {

@@ -314,3 +314,22 @@ def test_cpp_host_cli_renders_reference_ppm(tmp_path, oracle, book_scene):
     arr, n = book_scene
     m = oracle.render_mirror32(arr, n, oracle.book_camera(1.5), 90, 60, 3, 50)
     assert (vals == m[0]).all()
+
+
+def test_large_tables_and_material_variants(oracle):
+    """Tables beyond the LDS-resident size (the filter then takes k from SGPRs), a mid-size table
+    and the all metal/glass variant: same arithmetic, still bit-exact against the mirror."""
+    R = _R()
+    W, H, spp = 72, 48, 3
+    with R.Renderer(0) as r:
+        r.setCamera(R.bookCamera(W / H))
+        for kw, okw in (({"halfExtent": 35}, {"half_extent": 35}),                      # 4 8xx spheres > 4096
+                        ({"halfExtent": 20}, {"half_extent": 20}),
+                        ({"lambertBelow": 0.0, "metalBelow": 0.5}, {"lambert_below": 0.0, "metal_below": 0.5})):
+            r.setWorld(R.randomScene(**kw))
+            arr, n, _, _ = oracle.random_scene(**okw)
+            assert r.n_spheres == n
+            got = r.renderRows(W, H, spp, 50, want_accum=True, want_hit_id=True)
+            ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, spp, 50, threads=16)
+            _check_bit_exact(got, ref)
+            assert r.stats()["ray_segments"] == ref[3]

@@ -236,3 +236,16 @@ def test_mirror32_small_scenes_track_ref64(oracle):
     r32 = oracle.render_mirror32(arr, n, cam, 64, 32, 16, 50)
     assert (r64[2] == r32[2]).mean() > 0.995
     assert _psnr(r64[0], r32[0]) >= 40.0
+
+
+def test_mirror32_tracks_ref64_on_a_wide_scene(oracle):
+    """A 41 x 41 grid (1.6k spheres, centres out to |c| = 29): the filter margin grows with the
+    extent of the scene; hits must still agree with the FP64 restatement."""
+    arr, n, _, _ = oracle.random_scene(half_extent=20)
+    W, H, spp = 90, 60, 8
+    cam = oracle.book_camera(W / H)
+    r64 = oracle.render_ref64(arr, n, cam, W, H, spp, 50)
+    r32 = oracle.render_mirror32(arr, n, cam, W, H, spp, 50)
+    assert _psnr(r64[0], r32[0]) >= 40.0
+    assert np.mean(r64[2] != r32[2]) < 2e-3
+    assert abs(r64[3] - r32[3]) / r64[3] < 5e-3
