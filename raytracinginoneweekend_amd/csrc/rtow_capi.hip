@@ -151,7 +151,8 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   std::vector<rtow::SphereShade> shade((size_t)(n > 0 ? n : 1));
   std::vector<rtow::BigSphere> big;
   for (int j = 0; j < n_alloc; ++j) geom_at(j, 3) = INFINITY;
-  std::vector<float> rr((size_t)n_alloc, 0.0f), nk((size_t)n_alloc, -INFINITY);
+  std::vector<float4> exact((size_t)n_alloc, make_float4(0.f, 0.f, 0.f, 0.f));
+  std::vector<float> nk((size_t)n_alloc, -INFINITY);
   float cmax = 0.0f;
   for (int j = 0; j < n; ++j) {
     const float r = radius[j];
@@ -160,7 +161,7 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     if (!is_big) {
       const double c2 = (double)cx[j] * cx[j] + (double)cy[j] * cy[j] + (double)cz[j] * cz[j];
       geom_at(j, 3) = (float)(c2 - (double)r * r);
-      rr[j] = r * r;
+      exact[j] = make_float4(cx[j], cy[j], cz[j], r * r);
       nk[j] = -geom_at(j, 3);
       const float reach = (float)std::sqrt(c2) + std::fabs(r);
       if (reach > cmax) cmax = reach;
@@ -176,12 +177,12 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     s.kind = kind[j]; s.ir = ir[j]; s.inv_ir = 1.0f / ir[j]; s.pad_ = 0.f;
   }
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
-  HIP_TRY(c->geom_rr.reserve(sizeof(float) * rr.size()));
+  HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
   HIP_TRY(c->big.reserve(sizeof(rtow::BigSphere) * (big.empty() ? 1 : big.size())));
   HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float) * geom.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->geom_rr.p, rr.data(), sizeof(float) * rr.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->geom_rr.p, exact.data(), sizeof(float4) * exact.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->geom_nk.p, nk.data(), sizeof(float) * nk.size(), hipMemcpyHostToDevice));
   c->cmax = cmax;
   HIP_TRY(hipMemcpy(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice));
@@ -237,7 +238,7 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
 
   rtow::TraceParams p;
   p.cam = c->cam;
-  p.geom = (const float*)c->geom.p; p.geom_rr = (const float*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
+  p.geom = (const float*)c->geom.p; p.geom_exact = (const float4*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
   p.cmax = c->cmax;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;

@@ -7,13 +7,14 @@ namespace rtow {
 
 constexpr int kTraceThreads = 256;   // 4 wavefronts per workgroup
 constexpr int kGeomPad = 8;
+constexpr int kCandDepth = 16;       // per-lane stack of filter survivors awaiting the exact test
 constexpr int kMaxSpheresKInLds = 4096;  // up to this many table entries the filter reads -k from LDS (16 KB)          // the regular sphere table is padded to a multiple of this
 
 struct TraceParams {
   CameraParams cam;
   const float* geom;         // n_geom_pad/4 groups of 16 floats (layout: scan_regular), list order
   const float* geom_nk;      // -k per list entry (n_geom_pad + 4 values): copied to LDS by each workgroup
-  const float* geom_rr;      // r^2 per list entry (n_geom_pad values), for the exact test
+  const float4* geom_exact;  // (cx, cy, cz, r^2) per list entry, fetched per lane for the exact test
   int n_geom_pad;
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin
   const BigSphere* big;      // spheres intersected in binary64

@@ -43,7 +43,6 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // constant address space: wave-uniform loads from it become s_load_dwordx16 into SGPRs
 typedef const f16v __attribute__((address_space(4)))* geom_ptr;
 typedef float f4v __attribute__((ext_vector_type(4)));
-typedef const f4v __attribute__((address_space(4)))* rr_ptr;  // r^2 of the four spheres of a group
 
 // per-ray operands of the packed filter, every component duplicated into both halves of a pair
 struct ScanRay {
@@ -93,31 +92,52 @@ static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, co
   return __builtin_elementwise_fma(n, n, t);
 }
 
-static __device__ __forceinline__ void exact_test(float cx, float cy, float cz, float rr, int j, f3 o, f3 u,
-                                                  float tmin, int prev, float& best, int& id) {
-  const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
-  float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
-  float m = fmaf(-ocx, ocx, rr); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
-  const float disc = fmaf(b, b, m);
-  float t;
-  const bool ok = regular_candidate(b, disc, tmin, j == prev, t);
-  offer(disc >= 0.0f && ok, t, j, best, id);
+// Spheres that pass the filter are not tested on the spot (only a few lanes of the wave would be
+// busy): each lane pushes the list index onto a private stack in LDS, and the stacks are drained
+// together - every lane runs the exact test on ITS next candidate, fetched from the per-sphere
+// record table - when a stack is about to fill up and at the end of the scan.  The closest-hit rule
+// (smaller t, then larger index) does not depend on the order candidates are offered in.
+struct CandStack {
+  uint32_t* slot;   // LDS: this lane's column of [kCandDepth][64]
+  uint32_t n;
+};
+
+static __device__ __forceinline__ void cand_push(CandStack& c, bool pass, int j) {
+  if (pass) c.slot[c.n * 64u] = (uint32_t)j;
+  c.n += pass ? 1u : 0u;
 }
 
-static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, int j, rr_ptr rr, const ScanRay& r,
-                                                  f3 o, f3 u, float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
+static __device__ __forceinline__ void cand_drain(CandStack& c, const float4* __restrict__ exact, f3 o, f3 u,
+                                                  float tmin, int prev, float& best, int& id) {
+  for (uint32_t i = 0; __ballot(i < c.n) != 0; ++i) {
+    if (i < c.n) {
+      const int j = (int)c.slot[i * 64u];
+      const float4 sp = exact[j];   // (cx, cy, cz, r^2)
+      const float ocx = o.x - sp.x, ocy = o.y - sp.y, ocz = o.z - sp.z;
+      float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
+      float m = fmaf(-ocx, ocx, sp.w); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
+      const float disc = fmaf(b, b, m);
+      float t;
+      const bool ok = regular_candidate(b, disc, tmin, j == prev, t);
+      offer(disc >= 0.0f && ok, t, j, best, id);
+    }
+  }
+  c.n = 0;
+}
+
+static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, int j, const float4* exact,
+                                                  CandStack& cand, const ScanRay& r, f3 o, f3 u, float tmin, int prev,
+                                                  float& best, int& id RTOW_PROF_PARAM) {
   const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, nk.xy, r);
   const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
   if (mx >= r.threshold) {
-    RTOW_COUNT(0, 1);  // lane 0 only sees its own entries; counters 9..11 are wave level
-    RTOW_COUNT(1, (__ballot(f0.x >= r.threshold) != 0) + (__ballot(f0.y >= r.threshold) != 0) + (__ballot(f1.x >= r.threshold) != 0) + (__ballot(f1.y >= r.threshold) != 0));
-    RTOW_COUNT(2, __popcll(__ballot(f0.x >= r.threshold)) + __popcll(__ballot(f0.y >= r.threshold)) + __popcll(__ballot(f1.x >= r.threshold)) + __popcll(__ballot(f1.y >= r.threshold)));
-    const f4v r4 = rr[j >> 2];
-    if (f0.x >= r.threshold) exact_test(grp.s0, grp.s2, grp.s4, r4.x, j, o, u, tmin, prev, best, id);
-    if (f0.y >= r.threshold) exact_test(grp.s1, grp.s3, grp.s5, r4.y, j + 1, o, u, tmin, prev, best, id);
-    if (f1.x >= r.threshold) exact_test(grp.s8, grp.sa, grp.sc, r4.z, j + 2, o, u, tmin, prev, best, id);
-    if (f1.y >= r.threshold) exact_test(grp.s9, grp.sb, grp.sd, r4.w, j + 3, o, u, tmin, prev, best, id);
+    RTOW_COUNT(0, 1);
+    if (__ballot(cand.n > (uint32_t)(kCandDepth - 4)) != 0) cand_drain(cand, exact, o, u, tmin, prev, best, id);
+    cand_push(cand, f0.x >= r.threshold, j);
+    cand_push(cand, f0.y >= r.threshold, j + 1);
+    cand_push(cand, f1.x >= r.threshold, j + 2);
+    cand_push(cand, f1.y >= r.threshold, j + 3);
   }
 }
 
@@ -130,9 +150,9 @@ static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, 
 // SGPR the subtraction would cost a packed instruction of its own.  Tables too large for LDS use
 // the SGPR copy of k (moved to VGPRs first; same arithmetic, two more instructions per group).
 template <bool K_LDS>
-static __device__ __forceinline__ void scan_regular(geom_ptr geom, rr_ptr rr, const f4v* nk_lds, int n_groups,
-                                                    float cmax, f3 o, f3 u, float tmin, int prev, float& best,
-                                                    int& id RTOW_PROF_PARAM) {
+static __device__ __forceinline__ void scan_regular(geom_ptr geom, const float4* exact, const f4v* nk_lds,
+                                                    CandStack& cand, int n_groups, float cmax, f3 o, f3 u, float tmin,
+                                                    int prev, float& best, int& id RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
   const ScanRay r = scan_ray(o, u, cmax);
   f16v ga = geom[0];
@@ -141,11 +161,12 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, rr_ptr rr, co
     const f16v gb = geom[g + 1];
     f4v kb;
     if (K_LDS) kb = nk_lds[g + 1]; else ka = f4v{-ga.s6, -ga.s7, -ga.se, -ga.sf};
-    group_test(ga, ka, 4 * g, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    group_test(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     ga = geom[g + 2];
     if (K_LDS) ka = nk_lds[g + 2]; else kb = f4v{-gb.s6, -gb.s7, -gb.se, -gb.sf};
-    group_test(gb, kb, 4 * g + 4, rr, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    group_test(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
   }
+  cand_drain(cand, exact, o, u, tmin, prev, best, id);
 }
 
 static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -180,13 +201,19 @@ static __device__ __forceinline__ void wave_flush(unsigned long long* accum, boo
 
 template <bool K_LDS>
 __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const TraceParams P) {
-  extern __shared__ f4v nk_lds[];   // K_LDS: -k per sphere, (n_geom_pad + 4) floats
+  // LDS: candidate stacks [4 waves][kCandDepth][64] first, then (K_LDS) -k per sphere
+  extern __shared__ f4v lds_raw[];
+  uint32_t* const stacks = (uint32_t*)lds_raw;
+  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * kCandDepth * 64 / 4;
   const uint32_t lane = threadIdx.x & 63u;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
-  const rr_ptr rr = (rr_ptr)(uintptr_t)P.geom_rr;
+  CandStack cand;
+  cand.slot = stacks + (threadIdx.x >> 6) * (kCandDepth * 64) + lane;
+  cand.n = 0;
   if (K_LDS) {
     const int n4 = P.n_geom_pad / 4 + 1;
-    for (int i = threadIdx.x; i < n4; i += kTraceThreads) nk_lds[i] = ((const f4v*)P.geom_nk)[i];
+    f4v* const dst = lds_raw + (kTraceThreads / 64) * kCandDepth * 64 / 4;
+    for (int i = threadIdx.x; i < n4; i += kTraceThreads) dst[i] = ((const f4v*)P.geom_nk)[i];
     __syncthreads();
   }
 
@@ -284,7 +311,7 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       }
     }
     const unsigned long long t_scan0 = RTOW_CLOCK();
-    if (alive) scan_regular<K_LDS>(geom, rr, nk_lds, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    if (alive) scan_regular<K_LDS>(geom, P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     const unsigned long long t_scan1 = RTOW_CLOCK();
     if (alive) {
       if (P.hit_id && first_sample && depth == P.max_depth) P.hit_id[accpix] = id;
@@ -330,14 +357,15 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
   if (i < n_channels) rgb[i] = (uint8_t)quantise_fix(accum[i], spp);
 }
 
-static size_t k_lds_bytes(int n_geom_pad) { return sizeof(float) * (size_t)(n_geom_pad + 4); }
+static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * kCandDepth * 64; }
+static size_t k_lds_bytes(int n_geom_pad) { return stack_lds_bytes() + sizeof(float) * (size_t)(n_geom_pad + 4); }
 
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream) {
   if (p.n_geom_pad <= kMaxSpheresKInLds)
     hipLaunchKernelGGL(rtow_trace_kernel<true>, dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
                        stream, p);
   else
-    hipLaunchKernelGGL(rtow_trace_kernel<false>, dim3(grid_blocks), dim3(kTraceThreads), 0, stream, p);
+    hipLaunchKernelGGL(rtow_trace_kernel<false>, dim3(grid_blocks), dim3(kTraceThreads), stack_lds_bytes(), stream, p);
 }
 
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
@@ -361,7 +389,7 @@ int trace_blocks_per_cu(int n_geom_pad) {
   if (n_geom_pad <= kMaxSpheresKInLds)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true>, kTraceThreads, k_lds_bytes(n_geom_pad));
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false>, kTraceThreads, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false>, kTraceThreads, stack_lds_bytes());
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
