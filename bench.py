@@ -37,6 +37,19 @@ WORKLOADS = {
 }
 
 
+def hbm_traffic(workload, spp, world):
+    """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as gfx950 requires, WRITE_SIZE as is); only valid for the configuration it
+    was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world != 1 or spp != WORKLOADS[workload][2] or not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if t.get("workload") != workload:
+        return None
+    return t["fetch_bytes"] + t["write_bytes"]
+
+
 def cpu_baseline(width, height, depth, seed):
     """Time the FP64 restatement of the reference on a bounded sample: 16 rows spread over the
     frame.  Single thread first (the reference is single-threaded), then all host cores."""
@@ -200,7 +213,7 @@ def main():
                 "measured_peak_v_pk_fma_f32": 147.7,
                 "flop_per_segment": flop_per_segment,
                 "kernel_ms": avg_trace_s * 1e3,
-                "traffic": None,
+                "traffic": hbm_traffic(args.workload, spp, world),
                 "framebuffer_GBps": (n_rows * width * 3) / (sum(total_ms) / len(total_ms) * 1e-3) / 1e9,
             },
             "cpu_baseline": None,
