@@ -65,6 +65,48 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, int iters, unsign
             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
             : "v"(m), "v"(c));
       }
+    } else if (MODE == 4) {
+      // v_pk_fma_f32 with an SGPR-pair source (the filter's operand mix)
+      const f2 sp = {__builtin_amdgcn_readfirstlane(i) * 1e-9f + 0.999f, 0.998f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile(
+            "v_pk_fma_f32 %0, %8, %0, %9\n v_pk_fma_f32 %1, %8, %1, %9\n"
+            "v_pk_fma_f32 %2, %8, %2, %9\n v_pk_fma_f32 %3, %8, %3, %9\n"
+            "v_pk_fma_f32 %4, %8, %4, %9\n v_pk_fma_f32 %5, %8, %5, %9\n"
+            "v_pk_fma_f32 %6, %8, %6, %9\n v_pk_fma_f32 %7, %8, %7, %9\n"
+            : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+            : "s"(sp), "v"(cc));
+      }
+    } else if (MODE == 5) {
+      // v_pk_mul_f32 / v_pk_add_f32 mix
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile(
+            "v_pk_mul_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %9\n"
+            "v_pk_mul_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %9\n"
+            "v_pk_mul_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %9\n"
+            "v_pk_mul_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %9\n"
+            : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+            : "v"(mm), "v"(cc));
+      }
+    } else if (MODE == 6) {
+      // integer multiply rate
+      unsigned x0 = __float_as_uint(a0), x1 = __float_as_uint(a1), x2 = __float_as_uint(a2), x3 = __float_as_uint(a3);
+      unsigned x4 = __float_as_uint(a4), x5 = __float_as_uint(a5), x6 = __float_as_uint(a6), x7 = __float_as_uint(a7);
+      unsigned mk = 0x7feb352du;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile(
+            "v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n"
+            "v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+            "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n"
+            "v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+            : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+            : "v"(mk));
+      }
+      a0 = __uint_as_float(x0); a1 = __uint_as_float(x1); a2 = __uint_as_float(x2); a3 = __uint_as_float(x3);
+      a4 = __uint_as_float(x4); a5 = __uint_as_float(x5); a6 = __uint_as_float(x6); a7 = __uint_as_float(x7);
     } else {
       // 32 VALU instructions ~ 3 test bodies, no branch: ray in a1..a6 (o,d), sphere in s[..] via "s" operands
       float sx = __builtin_amdgcn_readfirstlane(i) * 1e-9f, sw = 0.04f;
@@ -230,6 +272,9 @@ static void launch_rate(void* p) {
     case 1: hipLaunchKernelGGL(rate_kernel<1>, g, b, 0, 0, c->out, c->iters, c->clk); break;
     case 2: hipLaunchKernelGGL(rate_kernel<2>, g, b, 0, 0, c->out, c->iters, c->clk); break;
     case 3: hipLaunchKernelGGL(rate_kernel<3>, g, b, 0, 0, c->out, c->iters, c->clk); break;
+    case 4: hipLaunchKernelGGL(rate_kernel<4>, g, b, 0, 0, c->out, c->iters, c->clk); break;
+    case 5: hipLaunchKernelGGL(rate_kernel<5>, g, b, 0, 0, c->out, c->iters, c->clk); break;
+    case 6: hipLaunchKernelGGL(rate_kernel<6>, g, b, 0, 0, c->out, c->iters, c->clk); break;
   }
 }
 
@@ -257,15 +302,15 @@ int main() {
   // (1) raw rates
   float* d_out; CK(hipMalloc(&d_out, sizeof(float) * 256 * CU * 8));
   unsigned long long* d_clk; CK(hipMalloc(&d_clk, 16));
-  const char* rn[] = {"v_fma_f32(vop3)", "v_pk_fma_f32", "v_fmac_f32(vop2)", "test-body(11)"};
-  for (int mode = 0; mode < 4; ++mode)
+  const char* rn[] = {"v_fma_f32(vop3)", "v_pk_fma_f32", "v_fmac_f32(vop2)", "test-body(11)", "v_pk_fma(sgpr src)", "v_pk_mul/add", "v_mul_lo_u32"};
+  for (int mode = 0; mode < 7; ++mode)
     for (int wps = 1; wps <= 8; wps *= 2) {
       RateCtx c{d_out, 40000, CU * wps, 256, mode, d_clk};
       double s = run_timed(launch_rate, &c, 3);
       unsigned long long hclk[2]; CK(hipMemcpy(hclk, d_clk, 16, hipMemcpyDeviceToHost));
       double per = (mode == 3 ? 33 : 32);
       double instr = (double)c.blocks * 256 * c.iters * per;  // lane-instructions
-      double flops = instr * 2 * (mode == 1 ? 2 : 1);
+      double flops = instr * 2 * ((mode == 1 || mode == 4) ? 2 : 1);
       printf("rate %-17s waves/SIMD %d : %.3f ms  %.1f Glane-instr/s  %.1f TFLOP/s  | %.2f cyc/instr/wave  clk %.0f MHz\n",
              rn[mode], wps, s * 1e3, instr / s * 1e-9, flops / s * 1e-12,
              (double)hclk[0] / (c.iters * per), (double)hclk[0] / (double)hclk[1] * 100.0);
@@ -307,7 +352,7 @@ int main() {
   CK(hipMemcpy(d_rays, rays.data(), sizeof(float) * 6 * NR, hipMemcpyHostToDevice));
   const char* names[] = {"scalar(s_load)", "lds-broadcast", "packed(pk)", "scalar+max4", "scalar-pipelined"};
   std::vector<Hit> h0, h1;
-  for (int var = 0; var < 5; ++var)
+  for (int var = 0; var < (getenv("UBENCH_SCANS") ? 5 : 0); ++var)
     for (int wps = 1; wps <= 8; wps *= 2) {
       ScanCtx c{var == V_PACKED ? d_sphp : d_sph, N, d_rays, NR, d_hit, 512, CU * wps, var};
       double s = run_timed(launch_scan, &c, 3);
