@@ -11,6 +11,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built libraries (they are git-ignored): build them once, here, where
+    hipcc and gcc exist.  On a GPU box the prebuilt files travel with the tree and nothing happens."""
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "librtow_hip.so")
+    exe = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "rtow_raytracer")
+    if (not os.path.exists(lib) or not os.path.exists(exe)) and shutil.which("hipcc"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "raytracinginoneweekend_amd", "csrc"), "-s"])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
