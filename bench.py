@@ -126,9 +126,10 @@ def main():
     tile = 4
     rows = None if world == 1 else multigpu.tile_rows(height, world, rank, tile)
     n_rows = height if rows is None else len(rows)
-    local_rgb = None
+    local_rgb = gatherer = None
     if world > 1:
-        local_rgb = torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{device}")
+        gatherer = multigpu.TileGatherer(height, width, world, rank, f"cuda:{device}" if args.backend == "nccl" else "cpu", tile)
+        local_rgb = gatherer.local if args.backend == "nccl" else torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{device}")
 
     def sync_all():
         if world > 1:
@@ -142,7 +143,9 @@ def main():
         r.sync()
         st = r.stats()
         if world > 1:
-            multigpu.gather_image(local_rgb if args.backend == "nccl" else local_rgb.cpu(), height, width, world, rank, tile)
+            if args.backend != "nccl":
+                gatherer.local[:n_rows].copy_(local_rgb)
+            gatherer.gather()
         return st
 
     for _ in range(args.warmup):

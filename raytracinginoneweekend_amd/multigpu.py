@@ -49,3 +49,42 @@ def gather_image(local_rgb, height, width, world_size, rank, tile=4, group=None,
         rows = torch.from_numpy(tile_rows(height, world_size, r, tile).astype(np.int64)).to(local_rgb.device)
         full[rows] = recv[r][: len(rows)]
     return full
+
+
+class TileGatherer:
+    """gather_image with every buffer allocated once: the per-step cost is one collective and, on
+    the destination rank, one row scatter.  `local` is the tensor the renderer writes into (rows of
+    this rank first, padding rows after them)."""
+
+    def __init__(self, height, width, world_size, rank, device, tile=4, group=None, dst=0):
+        import torch
+        self.height, self.width, self.world, self.rank, self.tile = height, width, world_size, rank, tile
+        self.group, self.dst = group, dst
+        self.rows = tile_rows(height, world_size, rank, tile)
+        self.n_pad = padded_rows(height, world_size, tile)
+        self.local = torch.zeros((self.n_pad, width, 3), dtype=torch.uint8, device=device)
+        self.recv = torch.empty((world_size, self.n_pad, width, 3), dtype=torch.uint8, device=device)
+        self.full = torch.empty((height, width, 3), dtype=torch.uint8, device=device) if rank == dst else None
+        # destination row of every gathered row; padding rows point at a scratch row past the frame
+        if rank == dst:
+            index = torch.full((world_size, self.n_pad), height, dtype=torch.int64)
+            for r in range(world_size):
+                rr = tile_rows(height, world_size, r, tile)
+                index[r, : len(rr)] = torch.from_numpy(rr.astype(np.int64))
+            self.index = index.view(-1).to(device)
+            self.scratch = torch.empty((height + 1, width, 3), dtype=torch.uint8, device=device)
+
+    def gather(self):
+        """All ranks call this after their render has finished; returns the frame on `dst`."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return self.local[: len(self.rows)]
+        try:
+            dist.all_gather_into_tensor(self.recv.view(-1), self.local.view(-1), group=self.group)
+        except (RuntimeError, NotImplementedError):  # backends without the flat form (gloo)
+            dist.all_gather(list(self.recv.unbind(0)), self.local, group=self.group)
+        if self.rank != self.dst:
+            return None
+        self.scratch.index_copy_(0, self.index, self.recv.view(-1, self.width, 3))
+        self.full.copy_(self.scratch[: self.height])
+        return self.full

@@ -25,6 +25,16 @@ WORKER = textwrap.dedent("""
     rows = multigpu.tile_rows(H, world, rank, tile=4)
     rgb, _, _, seg = O.render_mirror32(arr, n, cam, W, H, spp, 50, rows=rows, threads=2)
     full = multigpu.gather_image(torch.from_numpy(rgb), H, W, world, rank, tile=4)
+    tg = multigpu.TileGatherer(H, W, world, rank, "cpu", tile=4)
+    tg.local[: len(rows)] = torch.from_numpy(rgb)
+    full2 = tg.gather()
+    assert (full2 is None) == (rank != 0)
+    if rank == 0:
+        assert torch.equal(full, full2)
+        tg.local[: len(rows)] = torch.from_numpy(rgb)   # reusable
+        assert torch.equal(tg.gather(), full)
+    else:
+        tg.gather()
     segs = torch.tensor([seg], dtype=torch.int64)
     dist.all_reduce(segs)
     if rank == 0:
