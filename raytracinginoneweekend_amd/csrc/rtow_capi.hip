@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -65,7 +66,7 @@ struct rtow_ctx {
   rtow::CameraParams cam;
 
   // per-render workspace
-  DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..11] chunk counter
+  DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
   uint64_t* host_counters = nullptr;          // pinned, 16 bytes
 
   // last render
@@ -190,6 +191,10 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     HIP_TRY(hipMemcpy(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice));
   c->n_spheres = n; c->n_geom_pad = n_pad; c->n_big = (int)big.size();
   c->blocks_per_cu = rtow::trace_blocks_per_cu(n_pad);
+  if (const char* cap = getenv("RTOW_BLOCKS_PER_CU")) {  // experiments only: cap the resident workgroups per CU
+    const int v = atoi(cap);
+    if (v >= 1 && v < c->blocks_per_cu) c->blocks_per_cu = v;
+  }
   c->have_scene = true;
   return RTOW_OK;
 }
@@ -222,11 +227,7 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   HIP_TRY(hipSetDevice(c->device));
   if (c->pending) HIP_TRY(hipStreamSynchronize(c->stream));
 
-  // work chunks: runs of chunk_paths consecutive paths in pixel-major order
-  const uint32_t chunk_paths = 512;
   const uint64_t total_paths = n_pixels * (uint64_t)spp;
-  const uint64_t n_chunks64 = (total_paths + chunk_paths - 1) / chunk_paths;
-  if (n_chunks64 >= 0xffff0000ull) return fail(RTOW_ERR_INVALID, "render: too many work chunks");
 
   HIP_TRY(c->accum.reserve(sizeof(unsigned long long) * 3 * (n_pixels ? n_pixels : 1)));
   HIP_TRY(c->rgb.reserve(3 * (n_pixels ? n_pixels : 1)));
@@ -245,9 +246,11 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth;
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
   p.rows = rows ? (const int32_t*)c->rows.p : nullptr; p.n_rows = n_rows;
-  p.n_chunks = (uint32_t)n_chunks64; p.chunk_paths = chunk_paths; p.total_paths = total_paths;
+  p.chunk_max = 512;
+  p.chunk_min = 64; p.total_paths = total_paths;
+  p.inv_spp = (uint32_t)((0x100000000ull + (uint64_t)spp - 1) / (uint64_t)spp);
   p.seg_counter = (unsigned long long*)c->counters.p;
-  p.chunk_counter = (unsigned int*)((char*)c->counters.p + 8);
+  p.path_counter = (unsigned long long*)((char*)c->counters.p + 8);
   p.accum = (unsigned long long*)c->accum.p;
   p.hit_id = want_hit_id ? (int32_t*)c->hit_id.p : nullptr;
 
@@ -256,6 +259,7 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   int grid = c->n_cu * c->blocks_per_cu;
   const uint64_t blocks_needed = (waves_needed + (rtow::kTraceThreads / 64) - 1) / (rtow::kTraceThreads / 64);
   if ((uint64_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
+  p.n_waves = (uint32_t)grid * (rtow::kTraceThreads / 64);
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemsetAsync(c->counters.p, 0, 16, c->stream));

@@ -24,9 +24,14 @@ struct TraceParams {
   uint32_t seed_lo, seed_hi;
   const int32_t* rows;       // image rows to render (0 = top), or nullptr for 0..n_rows-1
   int n_rows;
-  uint32_t n_chunks, chunk_paths;   // work is handed out in runs of chunk_paths consecutive paths
+  // Work is handed out in runs ("chunks") of consecutive paths in pixel-major order, chunk_max
+  // paths at a time while plenty is left and down to chunk_min towards the end of the frame, so
+  // that the last waves to finish are at most one short chunk behind the others.
+  uint32_t chunk_max, chunk_min;    // multiples of 64, chunk_min <= chunk_max
+  uint32_t n_waves;                 // wavefronts in the grid
+  uint32_t inv_spp;                 // ceil(2^32 / spp): n / spp == mulhi(n, inv_spp) while n * spp < 2^32
   unsigned long long total_paths;   // n_rows * W * spp
-  unsigned int* chunk_counter;      // zeroed before launch
+  unsigned long long* path_counter; // next path to hand out; zeroed before launch
   unsigned long long* accum;        // n_rows*W*3 fixed-point sums, zeroed before launch
   int32_t* hit_id;                  // n_rows*W or nullptr
   unsigned long long* seg_counter;  // zeroed before launch

@@ -3,8 +3,8 @@
 //  rtow_trace_kernel   persistent waves; every lane carries one path (pixel, sample) through an
 //                      iterative bounce loop and is refilled with a new path the moment its
 //                      path ends, so the sphere scan always runs with full wavefronts.  Work is
-//                      handed out in chunks (a run of samples of one pixel) from a global
-//                      counter.  Radiance is summed per lane in 64-bit fixed point; when lanes move
+//                      handed out in chunks (runs of consecutive paths, pixel-major) from a global
+//                      counter, in sizes that shrink as the frame runs out.  Radiance is summed per lane in 64-bit fixed point; when lanes move
 //                      on to another pixel their sums are combined with a wavefront reduction
 //                      and added to the frame with integer atomics, which makes the image
 //                      independent of scheduling, chunking and GPU count.
@@ -22,12 +22,21 @@ namespace rtow {
 // debug build only: [0] wave-level group slow-path entries, [1] wave-level candidate evaluations,
 // [2] lane-level candidate evaluations, [3] wave iterations, [4] lane iterations (alive lanes)
 __device__ unsigned long long g_prof[16];
+
 // wave-local accumulation (values are wave-uniform), flushed once when the wave retires
 #define RTOW_PROF_DECL unsigned long long prof_[16] = {0}
 #define RTOW_PROF_PARAM , unsigned long long (&prof_)[16]
 #define RTOW_PROF_ARG , prof_
 #define RTOW_COUNT(i, v) do { prof_[i] += (unsigned long long)(v); } while (0)
 #define RTOW_PROF_FLUSH() do { if ((threadIdx.x & 63u) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_prof[i_], prof_[i_]); } while (0)
+#define RTOW_CLOCK() __builtin_amdgcn_s_memtime()
+#elif defined(RTOW_PROFILE_TIMELINE)
+// timeline build: per-wave time stamps only (plain stores to distinct addresses, no shared counters)
+#define RTOW_PROF_DECL
+#define RTOW_PROF_PARAM
+#define RTOW_PROF_ARG
+#define RTOW_COUNT(i, v) do { } while (0)
+#define RTOW_PROF_FLUSH() do { } while (0)
 #define RTOW_CLOCK() __builtin_amdgcn_s_memtime()
 #else
 #define RTOW_PROF_DECL
@@ -36,6 +45,13 @@ __device__ unsigned long long g_prof[16];
 #define RTOW_COUNT(i, v) do { } while (0)
 #define RTOW_PROF_FLUSH() do { } while (0)
 #define RTOW_CLOCK() 0ull
+#endif
+
+#ifdef RTOW_PROFILE_TIMELINE
+// per wave, 12 slots: realtime stamps (100 MHz) at start [0], when the work counter ran dry [1], at
+// the end [2]; live lanes [3] and iterations [4] at that point, iterations at the end [5]; core-clock
+// stamps of the last iteration [6..9]; realtime at loop exit [10] and at the end of that iteration [11]
+__device__ unsigned long long g_wave_times[12 * 16384];
 #endif
 
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -217,10 +233,11 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
     __syncthreads();
   }
 
-  // wave-uniform: the chunk being handed out.  A chunk is a run of chunk_paths consecutive paths
-  // in pixel-major order (all samples of a pixel, then the next pixel of the row list).
+  // wave-uniform: the chunk being handed out.  A chunk is a run of consecutive paths in
+  // pixel-major order (all samples of a pixel, then the next pixel of the row list).
   uint32_t e_next = 0, e_end = 0;     // offsets inside the chunk
-  uint32_t p_base = 0, s_base = 0;    // pixel and sample of the chunk's first path
+  unsigned long long seen = 0;        // first path of this wave's previous chunk
+  uint32_t p_base = 0, s_base = 0;    // pixel (index in the row list's image) and sample of the chunk's first path
   uint32_t r_base = 0, i_base = 0;    // row (in the row list) and column of that pixel
   bool exhausted = false;
 
@@ -235,7 +252,14 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
   uint32_t accpix = 0xffffffffu;
   unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
   uint32_t nseg = 0;
+  float my_paths = 0.0f;              // paths this wave has been handed so far
+  const float inv_waves = 1.0f / (float)P.n_waves;
   RTOW_PROF_DECL;
+#ifdef RTOW_PROFILE_TIMELINE
+  const uint32_t wave_id = blockIdx.x * (kTraceThreads / 64) + (threadIdx.x >> 6);
+  if (lane == 0 && wave_id < 16384) g_wave_times[12 * wave_id] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long iters_ = 0;
+#endif
 
   for (;;) {
     const unsigned long long t_refill = RTOW_CLOCK();
@@ -245,42 +269,85 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       if (need == 0) break;
       if (e_next >= e_end) {
         if (exhausted) break;
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(P.chunk_counter, 1u);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= P.n_chunks) { exhausted = true; break; }
-        const unsigned long long first = (unsigned long long)c * P.chunk_paths;
+        // guided self-scheduling: a quarter of an even share of what was left when this wave
+        // last looked, clamped to [chunk_min, chunk_max] and rounded down to whole wavefronts
+        uint32_t want = P.chunk_max;
+        const unsigned long long left_seen = P.total_paths - seen;
+        if (left_seen < 4ull * P.n_waves * P.chunk_max) {
+          want = ((uint32_t)left_seen / (4u * P.n_waves)) & ~63u;
+          want = want < P.chunk_min ? P.chunk_min : want;
+        }
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(P.path_counter, (unsigned long long)want);
+        first = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(first >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)first);
+        if (first >= P.total_paths) {
+#ifdef RTOW_PROFILE_TIMELINE
+          {
+            const unsigned long long live_ = __popcll(__ballot(alive));
+            if (lane == 0 && wave_id < 16384) {
+              g_wave_times[12 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
+              g_wave_times[12 * wave_id + 3] = live_;
+              g_wave_times[12 * wave_id + 4] = iters_;
+            }
+          }
+#endif
+          exhausted = true;
+          break;
+        }
+        seen = first;
+        {
+          // The SIMD's arbiter serves its resident waves by priority, then age, and age never
+          // changes for persistent waves: left alone, the oldest wave of a SIMD runs ten times as
+          // many iterations as the youngest, which then sits on stale work when the frame runs out
+          // and keeps the grid alive for milliseconds.  Each wave therefore compares what it has
+          // consumed with an even share of what has been handed out and raises its priority when it
+          // is behind, lowers it when it is ahead.
+          const float ahead = my_paths - (float)first * inv_waves;
+          if (ahead < -512.0f) __builtin_amdgcn_s_setprio(3);
+          else if (ahead < 0.0f) __builtin_amdgcn_s_setprio(2);
+          else if (ahead < 512.0f) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+          my_paths += (float)want;
+        }
         const unsigned long long left = P.total_paths - first;
-        p_base = (uint32_t)(first / (uint32_t)P.spp);
-        s_base = (uint32_t)(first - (unsigned long long)p_base * (uint32_t)P.spp);
+        // Pixels are handed out from the LAST pixel of the row list backwards, so a frame ends on its
+        // top rows.  The waves retire only when their longest path has ended, and in the scenes this
+        // renderer is used on the top of the frame is sky (one segment per path) while the bottom is
+        // ground and spheres (paths of up to max_depth segments): finishing on cheap paths cuts the
+        // time the grid spends draining from milliseconds to one iteration.
+        const uint32_t p_seq = (uint32_t)(first / (uint32_t)P.spp);
+        s_base = (uint32_t)(first - (unsigned long long)p_seq * (uint32_t)P.spp);
+        p_base = (uint32_t)P.n_rows * (uint32_t)P.W - 1u - p_seq;
         r_base = p_base / (uint32_t)P.W;
         i_base = p_base - r_base * (uint32_t)P.W;
         e_next = 0;
-        e_end = left < P.chunk_paths ? (uint32_t)left : P.chunk_paths;
+        e_end = left < want ? (uint32_t)left : want;
       }
       const uint32_t avail = e_end - e_next;
       const uint32_t rank = lanes_below(need);
       const uint32_t cnt = (uint32_t)__popcll(need);
       const bool take = !alive && rank < avail;
       // (pixel, sample) of the path this lane would take: e counts samples from the first sample
-      // of the chunk's first pixel.  With spp >= chunk_paths it overflows spp at most once.
+      // of the chunk's first pixel.  With spp >= chunk_max it overflows spp at most once.
       const uint32_t e = s_base + e_next + (take ? rank : 0u);
       uint32_t dp, sample;
-      if ((uint32_t)P.spp >= P.chunk_paths) {
+      if ((uint32_t)P.spp >= P.chunk_max) {
         dp = e >= (uint32_t)P.spp ? 1u : 0u;
         sample = e - (dp ? (uint32_t)P.spp : 0u);
       } else {
-        dp = e / (uint32_t)P.spp;
+        // e < 2 * chunk_max + spp and spp < chunk_max here: exact (2^32 / 1 does not fit inv_spp)
+        dp = P.spp == 1 ? e : __umulhi(e, P.inv_spp);
         sample = e - dp * (uint32_t)P.spp;
       }
-      const uint32_t pix_local = p_base + dp;
+      const uint32_t pix_local = p_base - dp;
       // a lane that moves on to another pixel hands its sums over first
       wave_flush(P.accum, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
       if (take) {
         if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
-        uint32_t r = r_base, col = i_base + dp;
-        while (col >= (uint32_t)P.W) { col -= (uint32_t)P.W; ++r; }
-        const int ci = (int)col;
+        uint32_t r = r_base;
+        int ci = (int)i_base - (int)dp;
+        while (ci < 0) { ci += P.W; --r; }
         const int y = P.rows ? P.rows[r] : (int)r;
         g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample);
         camera_ray(P.cam, ci, P.H - 1 - y, P.W, P.H, g, o, d);
@@ -336,6 +403,14 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       }
     }
     RTOW_COUNT(3, 1);
+#ifdef RTOW_PROFILE_TIMELINE
+    ++iters_;
+    if (lane == 0 && wave_id < 16384 && exhausted) {
+      g_wave_times[12 * wave_id + 6] = t_seg; g_wave_times[12 * wave_id + 7] = t_scan0;
+      g_wave_times[12 * wave_id + 8] = t_scan1; g_wave_times[12 * wave_id + 9] = RTOW_CLOCK();
+      g_wave_times[12 * wave_id + 11] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     RTOW_COUNT(5, t_seg - t_refill);           // refill
     RTOW_COUNT(6, t_scan0 - t_seg);            // normalise + binary64 spheres
     RTOW_COUNT(7, t_scan1 - t_scan0);          // scan (filter + exact tests)
@@ -343,8 +418,17 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
     (void)t_refill; (void)t_seg; (void)t_scan0; (void)t_scan1;
   }
 
+#ifdef RTOW_PROFILE_TIMELINE
+  if (lane == 0 && wave_id < 16384) g_wave_times[12 * wave_id + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
   wave_flush(P.accum, accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
   RTOW_PROF_FLUSH();
+#ifdef RTOW_PROFILE_TIMELINE
+  if (lane == 0 && wave_id < 16384) {
+    g_wave_times[12 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();
+    g_wave_times[12 * wave_id + 5] = iters_;
+  }
+#endif
   // ray-segment count: wave reduction, one atomic per wave
   const unsigned long long total = wave_sum(nseg);
   if (lane == 0) atomicAdd(P.seg_counter, total);
@@ -379,6 +463,14 @@ void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_ch
 extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -2;
   if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
+
+#ifdef RTOW_PROFILE_TIMELINE
+extern "C" int rtow_debug_wave_times(unsigned long long* out, int n_waves) {
+  if (n_waves > 16384) n_waves = 16384;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), sizeof(unsigned long long) * 12 * n_waves) != hipSuccess) return -2;
   return 0;
 }
 #endif

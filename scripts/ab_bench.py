@@ -3,16 +3,18 @@ usage: ab_bench.py [--spp N] [--rounds R] [--workload C2|C3] lib_a.so lib_b.so .
 import argparse, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from raytracinginoneweekend_amd import _lib, raytracer as R
+from raytracinginoneweekend_amd import _lib, multigpu, raytracer as R
 ap = argparse.ArgumentParser()
 ap.add_argument("--spp", type=int, default=125)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--workload", default="C2")
+ap.add_argument("--share", type=int, default=1, help="render only rank 0's row tiles of an N-way split")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 scene = {"C2": lambda: R.randomScene(), "C3": lambda: R.randomScene(lambertBelow=0.0, metalBelow=0.5),
          "C5": lambda: R.randomScene(halfExtent=50)}[a.workload]()
 n = len(scene)
+rows = None if a.share == 1 else multigpu.tile_rows(800, a.share, 0, 4)
 rs = []
 for path in a.libs:
     r = R.Renderer(0, lib=_lib.load(os.path.abspath(path)))
@@ -22,7 +24,7 @@ for path in a.libs:
 times = [[] for _ in rs]; seg = [0] * len(rs)
 for _ in range(a.rounds):
     for k, r in enumerate(rs):
-        r.renderAsync(1200, 800, a.spp, 50); r.sync(); st = r.stats()
+        r.renderAsync(1200, 800, a.spp, 50, rows=rows); r.sync(); st = r.stats()
         times[k].append(st["trace_ms"]); seg[k] = st["ray_segments"]
 for k, path in enumerate(a.libs):
     med, mn = statistics.median(times[k]), min(times[k])
