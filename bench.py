@@ -6,13 +6,16 @@
 A step is one full render of the headline frame (book-1 final scene, 1200x800, spp 500,
 depth 50, 484 spheres, seed 0xE7): clear + trace + resolve on the GPU with scene and camera
 already resident; nothing crosses PCIe inside the timed region except the 16-byte counter
-read-back.  With N > 1 (launched by torch.distributed.run, one process per GPU) the same frame
+read-back.  Steps are kept two deep in flight (two contexts, each with its own stream and
+buffers, used in turn): the tail of a frame overlaps the start of the next one.  All K steps
+start and complete inside the timed region; `latency_ms_per_step` is one step on its own.  With N > 1 (launched by torch.distributed.run, one process per GPU) the same frame
 is sharded by interleaved row tiles and each step ends with the RCCL gather of the 8-bit rows,
 so total work is fixed ("strong" scaling, BASELINE config 4).
 
 Prints ONE JSON line on rank 0.  value = ray segments (world.hit queries) of all ranks / wall
 seconds / 1e6.  roofline: algorithmic FLOP (18 per ray-sphere test, 18*N+65 per segment) over
-the trace kernel's own duration, measured with HIP events on the stream it runs on.
+the trace kernel's own duration, measured with HIP events on the stream it runs on in two
+un-overlapped steps after the timed region.
 cpu_baseline: the FP64 CPU restatement of the reference (oracle/, "port") timed on this box's
 host cores on a bounded sample of the same frame.
 """
@@ -83,6 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline number)")
+    ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (contexts used in turn); 1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks "
@@ -119,17 +123,25 @@ def main():
 
     world_scene = R.randomScene(halfExtent=half_extent, lambertBelow=lam, metalBelow=met)
     n_spheres = len(world_scene)
-    r = R.Renderer(device)
-    r.setWorld(world_scene)
-    r.setCamera(R.bookCamera(width / height))
-
     tile = 4
     rows = None if world == 1 else multigpu.tile_rows(height, world, rank, tile)
     n_rows = height if rows is None else len(rows)
-    local_rgb = gatherer = None
-    if world > 1:
-        gatherer = multigpu.TileGatherer(height, width, world, rank, f"cuda:{device}" if args.backend == "nccl" else "cpu", tile)
-        local_rgb = gatherer.local if args.backend == "nccl" else torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{device}")
+
+    # Frames in flight: PIPELINE contexts (each its own stream, accumulators and image) take the
+    # steps in turn, so that the tail of one frame - a few wavefronts finishing their longest paths,
+    # the resolve kernel, the gather of the rows - overlaps the start of the next frame.
+    depth_in_flight = max(1, args.pipeline)
+    renderers, gatherers, images = [], [], []
+    for _ in range(depth_in_flight):
+        r = R.Renderer(device)
+        r.setWorld(world_scene)
+        r.setCamera(R.bookCamera(width / height))
+        renderers.append(r)
+        if world > 1:
+            g = multigpu.TileGatherer(height, width, world, rank, f"cuda:{device}" if args.backend == "nccl" else "cpu", tile)
+            gatherers.append(g)
+            images.append(g.local if args.backend == "nccl"
+                          else torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{device}"))
 
     def sync_all():
         if world > 1:
@@ -137,35 +149,52 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step():
-        r.renderAsync(width, height, spp, depth, seed, rows=rows,
-                      rgb_dev=None if local_rgb is None else local_rgb.data_ptr())
-        r.sync()
-        st = r.stats()
+    def enqueue(i):
+        k = i % depth_in_flight
+        renderers[k].renderAsync(width, height, spp, depth, seed, rows=rows,
+                                 rgb_dev=images[k].data_ptr() if images else None)
+
+    def finish(i):
+        k = i % depth_in_flight
+        renderers[k].sync()
+        st = renderers[k].stats()
         if world > 1:
             if args.backend != "nccl":
-                gatherer.local[:n_rows].copy_(local_rgb)
-            gatherer.gather()
+                gatherers[k].local[:n_rows].copy_(images[k])
+            gatherers[k].gather()
+            if args.backend == "nccl":
+                torch.cuda.current_stream().synchronize()  # the rows are read before this context renders again
         return st
 
-    for _ in range(args.warmup):
-        step()
+    def run(n_steps):
+        out = []
+        for i in range(n_steps):
+            if i >= depth_in_flight:
+                out.append(finish(i - depth_in_flight))
+            enqueue(i)
+        for i in range(max(0, n_steps - depth_in_flight), n_steps):
+            out.append(finish(i))
+        return out
+
+    run(args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    segments = 0
-    trace_ms = []
-    total_ms = []
-    for _ in range(args.steps):
-        st = step()
-        segments += st["ray_segments"]
-        trace_ms.append(st["trace_ms"])
-        total_ms.append(st["total_ms"])
-    if world > 1:
-        torch.cuda.synchronize()
+    stats = run(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
+    segments = sum(st["ray_segments"] for st in stats)
 
-    seg_per_step_local = segments / max(1, args.steps)
+    # one frame at a time, for the kernel's own duration (launches that overlap stretch each other)
+    # and for the latency of a single step
+    serial = []
+    t1 = time.perf_counter()
+    for i in range(2):
+        enqueue(i)
+        serial.append(finish(i))
+    serial_ms = (time.perf_counter() - t1) / 2 * 1e3
+    trace_ms = [st["trace_ms"] for st in serial]
+    total_ms = [st["total_ms"] for st in serial]
+
     if world > 1:
         red_dev = f"cuda:{device}" if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -178,7 +207,7 @@ def main():
     if rank == 0:
         flop_per_segment = FLOP_PER_TEST * n_spheres + FLOP_PER_SEGMENT_EXTRA
         avg_trace_s = sum(trace_ms) / len(trace_ms) * 1e-3
-        achieved = seg_per_step_local * flop_per_segment / avg_trace_s / 1e12
+        achieved = serial[-1]["ray_segments"] * flop_per_segment / avg_trace_s / 1e12
         paths = width * height * spp
         out = {
             "metric": "Mrays/sec (ray segments = world.hit queries) book-1 final scene 1200x800 spp500 depth50",
@@ -200,6 +229,8 @@ def main():
                 "parallelism": "single GPU" if world == 1 else (
                     f"interleaved {tile}-row tiles over {world} GPUs + RCCL all_gather of 8-bit rows" if args.backend == "nccl"
                     else f"REHEARSAL: {world} gloo ranks sharing devices (not a benchmark)"),
+                "frames_in_flight": depth_in_flight,
+                "latency_ms_per_step": serial_ms,
                 "paths_per_step": paths,
                 "segments_per_step": segments // max(1, args.steps),
                 "mean_segments_per_path": segments / max(1, args.steps) / paths,
@@ -225,7 +256,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(width, height, depth, seed)
         print(json.dumps(out), flush=True)
 
-    r.close()
+    for r in renderers:
+        r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
