@@ -165,6 +165,8 @@ static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, 
 // start as fma(cx, 2o.x, -k): a VALU instruction can read only one SGPR operand, so with k in an
 // SGPR the subtraction would cost a packed instruction of its own.  Tables too large for LDS use
 // the SGPR copy of k (moved to VGPRs first; same arithmetic, two more instructions per group).
+typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
+
 template <bool K_LDS>
 static __device__ __forceinline__ void scan_regular(geom_ptr geom, const float4* exact, const f4v* nk_lds,
                                                     CandStack& cand, int n_groups, float cmax, f3 o, f3 u, float tmin,
@@ -172,14 +174,20 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, const float4*
   if (n_groups <= 0) return;
   const ScanRay r = scan_ray(o, u, cmax);
   f16v ga = geom[0];
-  f4v ka = K_LDS ? nk_lds[0] : f4v{0, 0, 0, 0};
+  // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
+  // immediate offsets.  (Left to itself the compiler keeps the address in an SGPR and copies it to
+  // a VGPR for every read: one more VALU instruction per group.)
+  uint32_t nk_addr = K_LDS ? (uint32_t)(uintptr_t)(nk_lds_ptr)nk_lds : 0u;
+  asm volatile("" : "+v"(nk_addr));
+  nk_lds_ptr nk = (nk_lds_ptr)(uintptr_t)nk_addr;
+  f4v ka = K_LDS ? nk[0] : f4v{0, 0, 0, 0};
   for (int g = 0; g < n_groups; g += 2) {
     const f16v gb = geom[g + 1];
     f4v kb;
-    if (K_LDS) kb = nk_lds[g + 1]; else ka = f4v{-ga.s6, -ga.s7, -ga.se, -ga.sf};
+    if (K_LDS) kb = nk[1]; else ka = f4v{-ga.s6, -ga.s7, -ga.se, -ga.sf};
     group_test(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     ga = geom[g + 2];
-    if (K_LDS) ka = nk_lds[g + 2]; else kb = f4v{-gb.s6, -gb.s7, -gb.se, -gb.sf};
+    if (K_LDS) { ka = nk[2]; nk += 2; } else kb = f4v{-gb.s6, -gb.s7, -gb.se, -gb.sf};
     group_test(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
   }
   cand_drain(cand, exact, o, u, tmin, prev, best, id);
