@@ -3,7 +3,7 @@
 set -e
 export TMPDIR=/tmp
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_r01c
+OUT=$REPO/gpurun_out/prof_r01d
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.err

@@ -16,11 +16,24 @@ if os.path.exists(trace):
     for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         lines.append(",".join(str(x) for x in r))
     lines.append("")
-    lines.append("# dispatches of the trace kernel")
-    lines.append("name,duration_ns,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size")
-    for r in c.execute("select name,duration,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size "
-                       "from kernels where name like '%trace%' order by start"):
-        lines.append(",".join(str(x) for x in r))
+    lines.append("# dispatches of the trace kernel, in start order.  bench.py keeps two steps in flight, so launches of")
+    lines.append("# the timed region overlap their neighbours (overlap_ns > 0) and stretch each other; the last two launches")
+    lines.append("# run one at a time and are the ones roofline.kernel_ms is taken from")
+    lines.append("name,start_ns,duration_ns,overlap_with_previous_ns,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size")
+    rows = list(c.execute("select name,start,end,duration,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size "
+                          "from kernels where name like '%trace%' order by start"))
+    t0 = rows[0][1] if rows else 0
+    prev_end = None
+    alone = []
+    for k, r in enumerate(rows):
+        ov = max(0, prev_end - r[1]) if prev_end is not None else 0
+        nxt = rows[k + 1][1] if k + 1 < len(rows) else None
+        if ov == 0 and (nxt is None or nxt >= r[2]):
+            alone.append(r[3])
+        prev_end = r[2]
+        lines.append(",".join(str(x) for x in (r[0], r[1] - t0, r[3], ov) + tuple(r[4:])))
+    if alone:
+        lines.append(f"# launches that ran alone: {len(alone)}, average duration {sum(alone) / len(alone):.0f} ns")
 open(prefix + "_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
 
 pmc = {}
