@@ -20,4 +20,6 @@ proc rtow_set_scene*(ctx: RtowCtx, n: cint, cx, cy, cz, radius: ptr cfloat, kind
 proc rtow_set_camera*(ctx: RtowCtx, cam: ptr RtowCamera): cint {.importc, dynlib: rtowLib.}
 proc rtow_render*(ctx: RtowCtx, w, h, spp, maxDepth: cint, seed: uint64, rows: ptr int32, nRows: cint,
                   rgbOut: ptr uint8, accumOut: ptr uint64, hitIdOut: ptr int32): cint {.importc, dynlib: rtowLib.}
+proc rtow_render_multi*(ctxs: ptr RtowCtx, nCtx: cint, w, h, spp, maxDepth: cint, seed: uint64, tileRows: cint,
+                        rgb: ptr uint8, raySegments: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_get_stats*(ctx: RtowCtx, stats: ptr RtowStats): cint {.importc, dynlib: rtowLib.}

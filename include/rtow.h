@@ -109,6 +109,18 @@ int rtow_render_async(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uint6
                       const int32_t* rows, int n_rows, void* rgb_dev);
 int rtow_sync(rtow_ctx* ctx);
 
+/* One frame on several contexts at once - normally one context per GPU of this process, each
+ * holding the same scene and camera.  The rows of the image - the outer j loop of render
+ * (raytracer.nim:36) - are dealt to the contexts in interleaved tiles of tile_rows rows (tile t goes
+ * to context t mod n_ctx), every context renders its rows as rtow_render_async does, and the 8-bit
+ * rows are copied into rgb_out (host, h*w*3 bytes, top row first).  The image is byte-identical to
+ * what rtow_render produces on one context.  ray_segments_out (may be NULL) receives the total
+ * number of world.hit queries.  Each context's rtow_get_stats then describes its own share.
+ * Hosts that run one PROCESS per GPU use rtow_render_async with their own row list instead and
+ * exchange the rows themselves (the Python host does so with torch.distributed over RCCL). */
+int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth,
+                      uint64_t seed, int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out);
+
 /* Statistics of the last completed render (call after rtow_render or rtow_sync). */
 int rtow_get_stats(rtow_ctx* ctx, rtow_stats* out);
 

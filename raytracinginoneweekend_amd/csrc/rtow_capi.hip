@@ -313,6 +313,54 @@ int rtow_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed
   return RTOW_OK;
 }
 
+int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth, uint64_t seed,
+                      int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out) {
+  if (!ctxs || n_ctx < 1) return fail(RTOW_ERR_INVALID, "rtow_render_multi: no contexts");
+  if (tile_rows < 1) return fail(RTOW_ERR_INVALID, "rtow_render_multi: tile_rows = %d", tile_rows);
+  if (h < 2) return fail(RTOW_ERR_INVALID, "render: image %dx%d (width and height must be >= 2)", w, h);
+  for (int k = 0; k < n_ctx; ++k) {
+    if (!ctxs[k]) return fail(RTOW_ERR_INVALID, "rtow_render_multi: ctxs[%d] is NULL", k);
+    for (int j = 0; j < k; ++j)
+      if (ctxs[j] == ctxs[k]) return fail(RTOW_ERR_INVALID, "rtow_render_multi: ctxs[%d] and ctxs[%d] are the same context", j, k);
+  }
+  // rows of context k: tiles k, k + n_ctx, k + 2 n_ctx, ... (sky rows cost one segment per path and
+  // ground rows several, so contiguous bands would be unbalanced)
+  std::vector<std::vector<int32_t>> rows((size_t)n_ctx);
+  for (int y = 0; y < h; ++y) rows[(size_t)((y / tile_rows) % n_ctx)].push_back(y);
+  for (int k = 0; k < n_ctx; ++k) {
+    static const int32_t no_rows[1] = {0};  // a context left without rows still takes part (and reports zero segments)
+    const std::vector<int32_t>& r = rows[(size_t)k];
+    const int rc = enqueue_render(ctxs[k], w, h, spp, max_depth, seed, r.empty() ? no_rows : r.data(), (int)r.size(),
+                                  nullptr, false);
+    if (rc != RTOW_OK) {
+      for (int j = 0; j < k; ++j) (void)rtow_sync(ctxs[j]);
+      return rc;
+    }
+  }
+  uint64_t segments = 0;
+  int first_error = RTOW_OK;
+  std::vector<uint8_t> staging;
+  const size_t row_bytes = 3 * (size_t)w;
+  for (int k = 0; k < n_ctx; ++k) {
+    rtow_ctx* c = ctxs[k];
+    int rc = rtow_sync(c);   // every context is drained even after a failure
+    const std::vector<int32_t>& r = rows[(size_t)k];
+    if (rc == RTOW_OK && rgb_out && !r.empty()) {
+      staging.resize(row_bytes * r.size());
+      const hipError_t e = hipMemcpy(staging.data(), c->rgb.p, staging.size(), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = fail(RTOW_ERR_DEVICE, "rtow_render_multi: %s", hipGetErrorString(e));
+      else
+        for (size_t i = 0; i < r.size(); ++i)
+          memcpy(rgb_out + row_bytes * (size_t)r[i], staging.data() + row_bytes * i, row_bytes);
+    }
+    if (rc == RTOW_OK) segments += c->stats.ray_segments;
+    else if (first_error == RTOW_OK) first_error = rc;
+  }
+  if (first_error != RTOW_OK) return first_error;
+  if (ray_segments_out) *ray_segments_out = segments;
+  return RTOW_OK;
+}
+
 int rtow_get_stats(rtow_ctx* c, rtow_stats* out) {
   if (!c || !out) return fail(RTOW_ERR_INVALID, "rtow_get_stats: NULL argument");
   *out = c->stats;

@@ -1,10 +1,12 @@
 // Command-line driver: main of raytracer.nim (:113-138) with its constants as defaults.
 //   rtow_raytracer [--width W] [--ratio R] [--spp N] [--depth D] [--scene random|mix|redblue]
-//                  [--half-extent E] [--out file.ppm] [--device K] [--dump-scene]
+//                  [--half-extent E] [--out file.ppm] [--device K | --devices K0,K1,...] [--dump-scene]
+// --devices spreads the frame over several GPUs (an index may repeat); the image does not change.
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <string>
+#include <vector>
 #include "raytracer.hpp"
 
 using namespace rtowhost;
@@ -14,6 +16,7 @@ int main(int argc, char** argv) {
   double ratio = 3.0 / 2.0;
   std::string out = "/tmp/test_small.ppm", scene = "random";
   bool dump = false;
+  std::vector<int> devices;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto val = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -25,6 +28,13 @@ int main(int argc, char** argv) {
     else if (a == "--half-extent") halfExtent = std::atoi(val());
     else if (a == "--out") out = val();
     else if (a == "--device") device = std::atoi(val());
+    else if (a == "--devices") {
+      for (const char* p = val(); *p;) {
+        devices.push_back(std::atoi(p));
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+    }
     else if (a == "--dump-scene") dump = true;
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
@@ -44,6 +54,13 @@ int main(int argc, char** argv) {
     const Camera cam = scene == "random" ? bookCamera(ratio)
                        : scene == "mix"  ? initCamera(point(3, 3, 2), point(0, 0, -1), vec3(0, 1, 0), 20, ratio, 2.0, std::sqrt(27.0))
                                          : initCamera(point(0, 0, 0), point(0, 0, -1), vec3(0, 1, 0), 90, ratio, 0.0, 1.0);
+    if (!devices.empty()) {
+      uint64_t segments = 0;
+      renderMulti(img, out, world, cam, spp, depth, devices, kRenderSeed, &segments);
+      std::fprintf(stderr, "%dx%d spp %d depth %d, %d spheres on %zu contexts: %llu ray segments -> %s\n", img.width, img.height,
+                   spp, depth, world.len(), devices.size(), (unsigned long long)segments, out.c_str());
+      return 0;
+    }
     rtow_stats st{};
     render(img, out, world, cam, spp, depth, kRenderSeed, device, &st);
     std::fprintf(stderr, "%dx%d spp %d depth %d, %d spheres: %llu ray segments, trace %.3f ms (%.1f Mrays/s) -> %s\n", img.width,

@@ -53,6 +53,38 @@ inline std::vector<uint8_t> render(const Image& img, const std::string& f, const
   return rgb;
 }
 
+// The same frame spread over several GPUs of this process (devices[k] = HIP device index; an index
+// may repeat): one context per entry, rows dealt in interleaved 4-row tiles, image assembled on the
+// host.  The file is byte-identical to what render() writes.
+inline std::vector<uint8_t> renderMulti(const Image& img, const std::string& f, const HittablesList& world,
+                                        const Camera& camera, int samplesPerPixel, int maxDepth,
+                                        const std::vector<int>& devices, uint64_t seed = kRenderSeed,
+                                        uint64_t* raySegments = nullptr) {
+  std::vector<rtow_ctx*> ctxs;
+  std::vector<uint8_t> rgb((size_t)img.width * (size_t)img.height * 3);
+  auto destroyAll = [&]() { for (rtow_ctx* c : ctxs) rtow_destroy(c); };
+  try {
+    const HittablesList::Flat s = world.flatten();
+    const rtow_camera cam = camera.flat();
+    for (int device : devices) {
+      rtow_ctx* ctx = nullptr;
+      check(rtow_create(device, &ctx), "rtow_create");
+      ctxs.push_back(ctx);
+      check(rtow_set_scene(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
+                           s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene");
+      check(rtow_set_camera(ctx, &cam), "rtow_set_camera");
+    }
+    check(rtow_render_multi(ctxs.data(), (int)ctxs.size(), img.width, img.height, samplesPerPixel, maxDepth, seed, 4,
+                            rgb.data(), raySegments), "rtow_render_multi");
+  } catch (...) {
+    destroyAll();
+    throw;
+  }
+  destroyAll();
+  if (!f.empty()) writePPM(f, img.width, img.height, rgb);
+  return rgb;
+}
+
 inline HittablesList sceneRedBlue() {  // raytracer.nim:48-59
   HittablesList result = initHittables(0);
   const double R = std::cos(3.14159265358979323846 / 4.0);

@@ -110,6 +110,21 @@ class Renderer:
         return p.value
 
 
+def renderMulti(renderers, width, height, samplesPerPixel, maxDepth, seed=RENDER_SEED, tile=4):
+    """One frame on several Renderers of this process at once (normally one per GPU, each holding the
+    same world and camera): rows dealt in interleaved `tile`-row tiles, image assembled in host
+    memory.  Returns (rgb uint8 [height, width, 3], ray segments)."""
+    if not renderers:
+        raise ValueError("renderMulti: no renderers")
+    L = renderers[0]._lib
+    handles = (C.c_void_p * len(renderers))(*[r._h for r in renderers])
+    rgb = np.empty((height, width, 3), np.uint8)
+    seg = C.c_uint64(0)
+    _lib.check(L.rtow_render_multi(handles, len(renderers), width, height, samplesPerPixel, maxDepth, seed, tile,
+                                   rgb.ctypes.data, C.byref(seg)))
+    return rgb, seg.value
+
+
 def writeColor(f, color, samplesPerPixel):
     """raytracer.nim:22-28 for one pixel's colour sum (host side, binary64)."""
     scale = 1.0 / float(samplesPerPixel)

@@ -209,6 +209,50 @@ def test_row_subsets_and_partition_invariance(gpu_renderer, oracle, book_scene):
     assert part[0].shape == (0, W, 3)
 
 
+def test_render_multi_contexts_match_single_context(gpu_renderer, tmp_path):
+    """rtow_render_multi: several contexts (here all on device 0; one per GPU in production) share a
+    frame by interleaved row tiles and return the image a single context renders, byte for byte."""
+    import subprocess
+    from conftest import ROOT
+    from raytracinginoneweekend_amd import _lib
+    R = _R()
+    W, H, spp = 150, 101, 5   # 101 rows: the last tile is short
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    full = gpu_renderer.renderRows(W, H, spp, 50)[0]
+    seg_full = gpu_renderer.stats()["ray_segments"]
+    scene = R.randomScene()
+    for n_ctx, tile in ((1, 4), (2, 4), (3, 1), (5, 7), (2, 200)):
+        rs = []
+        for _ in range(n_ctx):
+            r = R.Renderer(0); r.setWorld(scene); r.setCamera(R.bookCamera(W / H)); rs.append(r)
+        rgb, seg = R.renderMulti(rs, W, H, spp, 50, tile=tile)
+        assert (rgb == full).all() and seg == seg_full
+        assert sum(r.stats()["ray_segments"] for r in rs) == seg_full
+        rgb2, _ = R.renderMulti(rs, W, H, spp, 50, tile=tile)   # contexts are reusable
+        assert (rgb2 == full).all()
+        if n_ctx == 2:
+            with pytest.raises(_lib.RtowError) as e:
+                R.renderMulti([rs[0], rs[0]], W, H, spp, 50)
+            assert e.value.status == -1
+            with pytest.raises(_lib.RtowError):
+                R.renderMulti(rs, W, H, spp, 50, tile=0)
+        for r in rs:
+            r.close()
+    with R.Renderer(0) as bare, R.Renderer(0) as ok:   # one context without a scene: clean error, the other is drained
+        ok.setWorld(scene); ok.setCamera(R.bookCamera(W / H))
+        with pytest.raises(_lib.RtowError) as e:
+            R.renderMulti([ok, bare], W, H, spp, 50)
+        assert e.value.status == -3
+        assert (ok.renderRows(W, H, spp, 50)[0] == full).all()
+    # the compiled host: --devices 0,0,0 writes the same file as --device 0
+    exe = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "rtow_raytracer")
+    a, b = str(tmp_path / "one.ppm"), str(tmp_path / "three.ppm")
+    common = ["--width", "90", "--ratio", "1.5", "--spp", "3", "--depth", "50"]
+    subprocess.check_call([exe] + common + ["--out", a])
+    subprocess.check_call([exe] + common + ["--devices", "0,0,0", "--out", b])
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
 def test_repeatable_and_seed_dependent(gpu_renderer):
     R = _R()
     gpu_renderer.setCamera(R.bookCamera(1.5))
