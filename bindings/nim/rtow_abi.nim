@@ -22,4 +22,5 @@ proc rtow_render*(ctx: RtowCtx, w, h, spp, maxDepth: cint, seed: uint64, rows: p
                   rgbOut: ptr uint8, accumOut: ptr uint64, hitIdOut: ptr int32): cint {.importc, dynlib: rtowLib.}
 proc rtow_render_multi*(ctxs: ptr RtowCtx, nCtx: cint, w, h, spp, maxDepth: cint, seed: uint64, tileRows: cint,
                         rgb: ptr uint8, raySegments: ptr uint64): cint {.importc, dynlib: rtowLib.}
+proc rtow_format_ppm*(ctx: RtowCtx, binary: cint, dst: cstring, capacity: uint64, length: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_get_stats*(ctx: RtowCtx, stats: ptr RtowStats): cint {.importc, dynlib: rtowLib.}

@@ -121,6 +121,16 @@ int rtow_sync(rtow_ctx* ctx);
 int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth,
                       uint64_t seed, int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out);
 
+/* The PPM file of the most recent render on this context, as the reference writes it: the header
+ * "P3\n{w} {rows}\n255\n" (raytracer.nim:35) followed by one "r g b\n" line per pixel
+ * (writeColor, raytracer.nim:28), rows in the order they were rendered.  The text is composed on the
+ * device (about 11 bytes per pixel, 100 MB at 3840x2160) and copied into out[0..*length).
+ * binary != 0 gives the P6 variant instead (same header with P6, then 3 raw bytes per pixel).
+ * out == NULL only reports *length.  capacity < *length is RTOW_ERR_INVALID (with *length set).
+ * Needs a render whose image stayed in the context (rtow_render, or rtow_render_async /
+ * rtow_render_multi with rgb_dev == NULL); waits for it if it is still running. */
+int rtow_format_ppm(rtow_ctx* ctx, int binary, char* out, uint64_t capacity, uint64_t* length);
+
 /* Statistics of the last completed render (call after rtow_render or rtow_sync). */
 int rtow_get_stats(rtow_ctx* ctx, rtow_stats* out);
 

@@ -66,6 +66,9 @@ struct rtow_ctx {
   rtow::CameraParams cam;
 
   // per-render workspace
+  DevBuf ppm_len, ppm_off, ppm_text;          // device-side PPM text of the last image (rtow_format_ppm)
+  uint64_t ppm_bytes = 0;                     // length of that text, 0 = not composed yet
+  bool image_in_workspace = false;            // the last render left its 8-bit image in `rgb`
   DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
   uint64_t* host_counters = nullptr;          // pinned, 16 bytes
 
@@ -118,6 +121,7 @@ int rtow_destroy(rtow_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
+  c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release();
   if (c->host_counters) (void)hipHostFree(c->host_counters);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -273,6 +277,8 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   HIP_TRY(hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(hipMemcpyAsync(c->host_counters, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
   c->pending = true;
+  c->image_in_workspace = rgb_dev == nullptr;
+  c->ppm_bytes = 0;
   c->last_w = w; c->last_h = h; c->last_spp = spp; c->last_rows = n_rows;
   return RTOW_OK;
 }
@@ -358,6 +364,50 @@ int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, i
   }
   if (first_error != RTOW_OK) return first_error;
   if (ray_segments_out) *ray_segments_out = segments;
+  return RTOW_OK;
+}
+
+int rtow_format_ppm(rtow_ctx* c, int binary, char* out, uint64_t capacity, uint64_t* length) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_format_ppm: ctx is NULL");
+  if (!out && !length) return fail(RTOW_ERR_INVALID, "rtow_format_ppm: out and length are both NULL");
+  if (c->last_w == 0) return fail(RTOW_ERR_STATE, "rtow_format_ppm: nothing has been rendered on this context");
+  if (!c->image_in_workspace)
+    return fail(RTOW_ERR_STATE, "rtow_format_ppm: the last render wrote its image to the caller's device buffer");
+  int rc = rtow_sync(c);
+  if (rc != RTOW_OK) return rc;
+  char header[64];
+  const int header_len = snprintf(header, sizeof(header), "P%c\n%d %d\n255\n", binary ? '6' : '3', c->last_w, c->last_rows);
+  const uint64_t n_pixels = (uint64_t)c->last_w * (uint64_t)c->last_rows;
+  uint64_t body = 3 * n_pixels;
+  if (!binary) {
+    if (c->ppm_bytes == 0 && n_pixels) {
+      const uint32_t n_blocks = (uint32_t)((n_pixels + rtow::kPpmBlock - 1) / rtow::kPpmBlock);
+      HIP_TRY(c->ppm_len.reserve(sizeof(uint32_t) * n_blocks));
+      HIP_TRY(c->ppm_off.reserve(sizeof(unsigned long long) * ((size_t)n_blocks + 1)));
+      rtow::launch_ppm_lengths((const uint8_t*)c->rgb.p, (uint32_t)n_pixels, (uint32_t*)c->ppm_len.p, c->stream);
+      rtow::launch_ppm_scan((const uint32_t*)c->ppm_len.p, n_blocks, (unsigned long long*)c->ppm_off.p, c->stream);
+      HIP_TRY(hipGetLastError());
+      unsigned long long total = 0;
+      HIP_TRY(hipMemcpyAsync(&total, (const unsigned long long*)c->ppm_off.p + n_blocks, sizeof(total),
+                             hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(c->ppm_text.reserve((size_t)total));
+      rtow::launch_ppm_text((const uint8_t*)c->rgb.p, (uint32_t)n_pixels, (const unsigned long long*)c->ppm_off.p,
+                            (char*)c->ppm_text.p, c->stream);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      c->ppm_bytes = total;
+    }
+    body = c->ppm_bytes;
+  }
+  const uint64_t total_len = (uint64_t)header_len + body;
+  if (length) *length = total_len;
+  if (!out) return RTOW_OK;
+  if (capacity < total_len)
+    return fail(RTOW_ERR_INVALID, "rtow_format_ppm: %llu bytes needed, capacity %llu", (unsigned long long)total_len,
+                (unsigned long long)capacity);
+  memcpy(out, header, (size_t)header_len);
+  if (body) HIP_TRY(hipMemcpy(out + header_len, binary ? c->rgb.p : c->ppm_text.p, (size_t)body, hipMemcpyDeviceToHost));
   return RTOW_OK;
 }
 

@@ -42,4 +42,14 @@ void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_ch
                     hipStream_t stream);
 int trace_blocks_per_cu(int n_geom_pad);
 
+// P3 text of an 8-bit image, one "r g b\n" line per pixel (raytracer.nim:28), formatted on the device.
+constexpr int kPpmBlock = 256;   // pixels per workgroup
+// pass 1: bytes of text per workgroup of pixels -> block_len[ceil(n_pixels / kPpmBlock)]
+void launch_ppm_lengths(const uint8_t* rgb, uint32_t n_pixels, uint32_t* block_len, hipStream_t stream);
+// pass 2: exclusive prefix sum of block_len -> block_off[n_blocks], grand total -> block_off[n_blocks]
+void launch_ppm_scan(const uint32_t* block_len, uint32_t n_blocks, unsigned long long* block_off, hipStream_t stream);
+// pass 3: the text itself, text[block_off[b] ...] for every workgroup b
+void launch_ppm_text(const uint8_t* rgb, uint32_t n_pixels, const unsigned long long* block_off, char* text,
+                     hipStream_t stream);
+
 }  // namespace rtow

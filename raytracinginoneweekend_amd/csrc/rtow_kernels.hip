@@ -467,6 +467,115 @@ void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_ch
                      n_channels, spp);
 }
 
+// ------------------------------------------------------------------ PPM text (raytracer.nim:28,35)
+// writeColor prints three decimal integers and a newline per pixel.  At 4K that is ~100 MB of
+// text, seconds of fprintf on the host; on the device it is a byte-shuffling pass bounded by HBM
+// (3 bytes read, 6-12 written per pixel): lengths per workgroup, a prefix sum, then every
+// workgroup composes its lines in LDS and stores them as one contiguous run.
+static __device__ __forceinline__ uint32_t dec_digits(uint32_t v) { return v >= 100u ? 3u : (v >= 10u ? 2u : 1u); }
+
+static __device__ __forceinline__ uint32_t pixel_text_len(const uint8_t* rgb, uint32_t pix, uint32_t n_pixels,
+                                                          uint32_t& r, uint32_t& g, uint32_t& b) {
+  if (pix >= n_pixels) { r = g = b = 0; return 0u; }
+  r = rgb[3ull * pix]; g = rgb[3ull * pix + 1]; b = rgb[3ull * pix + 2];
+  return dec_digits(r) + dec_digits(g) + dec_digits(b) + 3u;   // two blanks and the newline
+}
+
+// inclusive prefix sum over the kPpmBlock threads of a workgroup; returns this thread's inclusive
+// value, `total` = sum over the workgroup
+static __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* wave_tot, uint32_t& total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(v, off, 64);
+    if ((int)lane >= off) v += up;
+  }
+  if (lane == 63u) wave_tot[wave] = v;
+  __syncthreads();
+  uint32_t before = 0;
+  total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kPpmBlock / 64; ++w) {
+    const uint32_t t = wave_tot[w];
+    before += w < wave ? t : 0u;
+    total += t;
+  }
+  __syncthreads();
+  return v + before;
+}
+
+__global__ void __launch_bounds__(kPpmBlock) ppm_lengths_kernel(const uint8_t* __restrict__ rgb, uint32_t n_pixels,
+                                                               uint32_t* __restrict__ block_len) {
+  __shared__ uint32_t wave_tot[kPpmBlock / 64];
+  uint32_t r, g, b, total;
+  const uint32_t len = pixel_text_len(rgb, blockIdx.x * kPpmBlock + threadIdx.x, n_pixels, r, g, b);
+  (void)block_inclusive_scan(len, wave_tot, total);
+  if (threadIdx.x == 0) block_len[blockIdx.x] = total;
+}
+
+// one workgroup of 1024 threads: thread t owns a contiguous span of the entries
+__global__ void __launch_bounds__(1024) ppm_scan_kernel(const uint32_t* __restrict__ block_len, uint32_t n_blocks,
+                                                         unsigned long long* __restrict__ block_off) {
+  __shared__ unsigned long long span_sum[1024];
+  const uint32_t per = (n_blocks + 1023u) / 1024u;
+  const uint32_t lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+  unsigned long long s = 0;
+  for (uint32_t i = lo; i < hi; ++i) s += block_len[i];
+  span_sum[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) { const unsigned long long t = span_sum[i]; span_sum[i] = run; run += t; }
+    block_off[n_blocks] = run;
+  }
+  __syncthreads();
+  unsigned long long run = span_sum[threadIdx.x];
+  for (uint32_t i = lo; i < hi; ++i) { block_off[i] = run; run += block_len[i]; }
+}
+
+static __device__ __forceinline__ uint32_t put_decimal(char* dst, uint32_t at, uint32_t v, char after) {
+  if (v >= 100u) dst[at++] = (char)('0' + v / 100u);
+  if (v >= 10u) dst[at++] = (char)('0' + (v / 10u) % 10u);
+  dst[at++] = (char)('0' + v % 10u);
+  dst[at++] = after;
+  return at;
+}
+
+__global__ void __launch_bounds__(kPpmBlock) ppm_text_kernel(const uint8_t* __restrict__ rgb, uint32_t n_pixels,
+                                                            const unsigned long long* __restrict__ block_off,
+                                                            char* __restrict__ text) {
+  __shared__ uint32_t wave_tot[kPpmBlock / 64];
+  __shared__ char lines[kPpmBlock * 12];
+  uint32_t r, g, b, total;
+  const uint32_t len = pixel_text_len(rgb, blockIdx.x * kPpmBlock + threadIdx.x, n_pixels, r, g, b);
+  uint32_t at = block_inclusive_scan(len, wave_tot, total) - len;
+  if (len) {
+    at = put_decimal(lines, at, r, ' ');
+    at = put_decimal(lines, at, g, ' ');
+    (void)put_decimal(lines, at, b, '\n');
+  }
+  __syncthreads();
+  char* const dst = text + block_off[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < total; i += kPpmBlock) dst[i] = lines[i];
+}
+
+void launch_ppm_lengths(const uint8_t* rgb, uint32_t n_pixels, uint32_t* block_len, hipStream_t stream) {
+  if (n_pixels == 0) return;
+  hipLaunchKernelGGL(ppm_lengths_kernel, dim3((n_pixels + kPpmBlock - 1) / kPpmBlock), dim3(kPpmBlock), 0, stream, rgb,
+                     n_pixels, block_len);
+}
+
+void launch_ppm_scan(const uint32_t* block_len, uint32_t n_blocks, unsigned long long* block_off, hipStream_t stream) {
+  hipLaunchKernelGGL(ppm_scan_kernel, dim3(1), dim3(1024), 0, stream, block_len, n_blocks, block_off);
+}
+
+void launch_ppm_text(const uint8_t* rgb, uint32_t n_pixels, const unsigned long long* block_off, char* text,
+                     hipStream_t stream) {
+  if (n_pixels == 0) return;
+  hipLaunchKernelGGL(ppm_text_kernel, dim3((n_pixels + kPpmBlock - 1) / kPpmBlock), dim3(kPpmBlock), 0, stream, rgb,
+                     n_pixels, block_off, text);
+}
+
 #ifdef RTOW_PROFILE_COUNTERS
 extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -2;

@@ -44,12 +44,21 @@ inline std::vector<uint8_t> render(const Image& img, const std::string& f, const
     check(rtow_render(ctx, img.width, img.height, samplesPerPixel, maxDepth, seed, nullptr, img.height,
                       rgb.data(), nullptr, nullptr), "rtow_render");
     if (stats) check(rtow_get_stats(ctx, stats), "rtow_get_stats");
+    if (!f.empty()) {  // the P3 text is composed on the device; writePPM() above is its host-side equivalent
+      uint64_t n = 0;
+      check(rtow_format_ppm(ctx, 0, nullptr, 0, &n), "rtow_format_ppm");
+      std::vector<char> text((size_t)n);
+      check(rtow_format_ppm(ctx, 0, text.data(), n, &n), "rtow_format_ppm");
+      FILE* out = std::fopen(f.c_str(), "wb");
+      if (!out) throw std::runtime_error("cannot open " + f);
+      const size_t put = std::fwrite(text.data(), 1, text.size(), out);
+      if (std::fclose(out) != 0 || put != text.size()) throw std::runtime_error("cannot write " + f);
+    }
   } catch (...) {
     rtow_destroy(ctx);
     throw;
   }
   rtow_destroy(ctx);
-  if (!f.empty()) writePPM(f, img.width, img.height, rgb);
   return rgb;
 }
 

@@ -98,6 +98,15 @@ class Renderer:
     def sync(self):
         _lib.check(self._lib.rtow_sync(self._h))
 
+    def ppm(self, binary=False):
+        """The PPM file of the last render as bytes: P3 text exactly as the reference prints it
+        (raytracer.nim:28,35), composed on the device; binary=True gives P6."""
+        n = C.c_uint64(0)
+        _lib.check(self._lib.rtow_format_ppm(self._h, int(binary), None, 0, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        _lib.check(self._lib.rtow_format_ppm(self._h, int(binary), buf.ctypes.data, n.value, C.byref(n)))
+        return buf.tobytes()
+
     def stats(self):
         s = _lib.Stats()
         _lib.check(self._lib.rtow_get_stats(self._h, C.byref(s)))
@@ -154,8 +163,9 @@ def render(img, f, world, camera, samplesPerPixel, maxDepth, seed=RENDER_SEED, d
         r.setWorld(world)
         r.setCamera(camera)
         rgb, _, _ = r.renderRows(img.width, img.height, samplesPerPixel, maxDepth, seed)
-    with open(f, "w") as out:
-        writePPM(out, rgb)
+        text = r.ppm()   # the file's bytes come from the device too; writePPM is the host-side equivalent
+    with open(f, "wb") as out:
+        out.write(text)
     return rgb
 
 

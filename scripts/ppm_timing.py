@@ -1,0 +1,16 @@
+"""Time the device-side PPM text (rtow_format_ppm) against the host writers at 1200x800 and 3840x2160."""
+import io, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracinginoneweekend_amd import raytracer as R
+r = R.Renderer(0); r.setWorld(R.randomScene())
+for W, H in ((1200, 800), (3840, 2160)):
+    r.setCamera(R.bookCamera(W / H))
+    rgb = r.renderRows(W, H, 1, 50)[0]
+    t0 = time.perf_counter(); text = r.ppm(); t1 = time.perf_counter() - t0
+    r.renderRows(W, H, 1, 50)
+    t0 = time.perf_counter(); text = r.ppm(); t1b = time.perf_counter() - t0
+    t0 = time.perf_counter(); p6 = r.ppm(binary=True); t2 = time.perf_counter() - t0
+    t0 = time.perf_counter(); s = io.StringIO(); R.writePPM(s, rgb); t3 = time.perf_counter() - t0
+    print(f"{W}x{H}: P3 {len(text)/1e6:.1f} MB device+copy {t1*1e3:.1f} ms (2nd frame {t1b*1e3:.1f} ms), P6 {t2*1e3:.1f} ms, "
+          f"Python host writer {t3*1e3:.0f} ms", flush=True)

@@ -345,6 +345,38 @@ def test_render_writes_reference_style_ppm(tmp_path, oracle, book_scene):
     assert (vals == m[0]).all() and (rgb == m[0]).all()
 
 
+def test_device_side_ppm_text_matches_host_writer(gpu_renderer):
+    """rtow_format_ppm: the P3 text composed on the device equals the host writer's (the reference's
+    header and one 'r g b' line per pixel) byte for byte; P6 carries the same pixels."""
+    import io
+    from raytracinginoneweekend_amd import _lib
+    R = _R()
+    for W, H, spp, rows in ((150, 100, 2, None), (257, 3, 1, None), (1200, 800, 1, None), (64, 48, 1, [5, 0, 47])):
+        gpu_renderer.setCamera(R.bookCamera(W / H))
+        rgb = gpu_renderer.renderRows(W, H, spp, 50, rows=rows)[0]
+        host = io.StringIO()
+        R.writePPM(host, rgb)
+        text = gpu_renderer.ppm()
+        assert text == host.getvalue().encode()
+        assert gpu_renderer.ppm() == text                     # cached text, second call
+        p6 = gpu_renderer.ppm(binary=True)
+        head = f"P6\n{W} {rgb.shape[0]}\n255\n".encode()
+        assert p6.startswith(head) and p6[len(head):] == rgb.tobytes()
+        if W == 1200:   # one-, two- and three-digit values all occur in a full frame
+            vals = set(text.split()[4:])
+            assert {b"0", b"255"} <= vals and any(len(v) == 2 for v in vals)
+    n = _lib.C.c_uint64(0)
+    with pytest.raises(_lib.RtowError) as e:   # buffer too small: error, needed length still reported
+        _lib.check(gpu_renderer._lib.rtow_format_ppm(gpu_renderer._h, 0, np.empty(8, np.uint8).ctypes.data, 8, _lib.C.byref(n)))
+    assert e.value.status == -1 and n.value == len(text)
+    with R.Renderer(0) as fresh:
+        with pytest.raises(_lib.RtowError) as e:
+            fresh.ppm()
+        assert e.value.status == -3
+    gpu_renderer.renderRows(64, 48, 1, 50, rows=[])
+    assert gpu_renderer.ppm() == b"P3\n64 0\n255\n"
+
+
 def test_cpp_host_cli_renders_reference_ppm(tmp_path, oracle, book_scene):
     """The compiled host (rtow_raytracer = main of raytracer.nim above the C ABI) end to end."""
     import subprocess
