@@ -116,6 +116,36 @@ static inline f3 unit_ball(stream* g, float* l2_out) {
   }
 }
 
+/* Audit of the screen (tests only).  mode 0: normal.  mode 1: the screen is evaluated but never
+ * rejects - every sphere gets the exact test - and every sphere whose exact discriminant is >= 0 is
+ * tallied: how many of them the screen would have dropped (must stay 0), and how far above the
+ * threshold the closest one sat, in units of the margin (1 = no rounding error at all, 0 = the
+ * margin is used up). */
+static atomic_int g_audit_mode;
+static atomic_ullong g_audit_true_hits, g_audit_dropped;
+static _Atomic double g_audit_min_slack;
+
+void orc_mirror32_filter_audit(int mode) {
+  atomic_store(&g_audit_mode, mode);
+  atomic_store(&g_audit_true_hits, 0ull);
+  atomic_store(&g_audit_dropped, 0ull);
+  atomic_store(&g_audit_min_slack, 1e30);
+}
+
+void orc_mirror32_filter_audit_result(uint64_t* true_hits, uint64_t* dropped, double* min_slack_in_margins) {
+  *true_hits = atomic_load(&g_audit_true_hits);
+  *dropped = atomic_load(&g_audit_dropped);
+  *min_slack_in_margins = atomic_load(&g_audit_min_slack);
+}
+
+static void audit_note(float filter_value, float threshold, float margin_abs) {
+  atomic_fetch_add(&g_audit_true_hits, 1ull);
+  if (!(filter_value >= threshold)) atomic_fetch_add(&g_audit_dropped, 1ull);
+  const double slack = ((double)filter_value - (double)threshold) / (double)margin_abs;
+  double cur = atomic_load(&g_audit_min_slack);
+  while (slack < cur && !atomic_compare_exchange_weak(&g_audit_min_slack, &cur, slack)) { }
+}
+
 /* closest hit over the whole list: candidate of a sphere is its near root if >= tmin, else its
  * far root if >= tmin (hitrecord.nim:66-71); minimum wins, ties go to the later index
  * (hittables.nim:84-88) */
@@ -128,18 +158,22 @@ static int closest_hit(const sph32* w, int n, float cmax, f3 o, f3 u, float tmin
   const float ox2 = 2.0f * o.x, oy2 = 2.0f * o.y, oz2 = 2.0f * o.z;
   const float oo = dot3(o, o);
   const float reach = sqrtf(oo) + cmax;
-  const float threshold = oo - FILTER_MARGIN * (reach * reach);
+  const float margin_abs = FILTER_MARGIN * (reach * reach);
+  const float threshold = oo - margin_abs;
+  const int audit = atomic_load(&g_audit_mode);
   for (int j = 0; j < n; ++j) {
     float t;
     if (!w[j].big) {
       float fn = fmaf(w[j].cx, u.x, nou); fn = fmaf(w[j].cy, u.y, fn); fn = fmaf(w[j].cz, u.z, fn);
       float ft = fmaf(w[j].cx, ox2, -w[j].k); ft = fmaf(w[j].cy, oy2, ft); ft = fmaf(w[j].cz, oz2, ft);
-      if (!(fmaf(fn, fn, ft) >= threshold)) continue;
+      const float fv = fmaf(fn, fn, ft);
+      if (!audit && !(fv >= threshold)) continue;
       const float ocx = o.x - w[j].cx, ocy = o.y - w[j].cy, ocz = o.z - w[j].cz;
       float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
       float m = fmaf(-ocx, ocx, w[j].r2); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
       const float disc = fmaf(b, b, m);
       if (!(disc >= 0.0f)) continue;
+      if (audit) audit_note(fv, threshold, margin_abs);
       if (j == prev) {
         t = -2.0f * b; /* origin lies on this sphere: roots are 0 and -2b */
         if (t < tmin) continue;

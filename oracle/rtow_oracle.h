@@ -100,6 +100,14 @@ int orc_mirror32_render(const orc_sphere* spheres, int n_spheres, const orc_came
                         const int32_t* rows, int n_rows, int n_threads,
                         uint8_t* rgb, uint64_t* accum_fix, int32_t* hit_id, uint64_t* ray_segments);
 
+/* Audit of the mirror's sphere screen (n^2 + (2o).c - k >= |o|^2 - margin), for tests.  mode 1:
+ * the screen stops rejecting and every sphere with an exact discriminant >= 0 is tallied until
+ * mode 0 is set again; _result reports how many there were, how many the screen would have
+ * dropped (the renderer is only correct while that is 0) and the smallest (value - threshold) /
+ * margin among them (1 = no rounding error, 0 = margin used up).  Process-wide state. */
+void orc_mirror32_filter_audit(int mode);
+void orc_mirror32_filter_audit_result(uint64_t* true_hits, uint64_t* dropped, double* min_slack_in_margins);
+
 /* One path in isolation: writes the list index hit by every segment (-1 = sky) into trail[]
  * (at most trail_cap entries) and returns the number of segments. */
 int orc_ref64_trace_path(const orc_sphere* spheres, int n_spheres, const orc_camera* cam, int W, int H,

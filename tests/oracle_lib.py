@@ -81,6 +81,10 @@ def lib():
     L.orc_mirror32_render.argtypes = [C.POINTER(Sphere), C.c_int, C.POINTER(Camera), C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_mirror32_filter_audit.argtypes = [C.c_int]
+    L.orc_mirror32_filter_audit.restype = None
+    L.orc_mirror32_filter_audit_result.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.orc_mirror32_filter_audit_result.restype = None
     L.orc_ref64_sphere_hit.argtypes = [C.POINTER(Sphere), dp, dp, C.c_double, C.c_double, dp, dp, dp,
                                        C.POINTER(C.c_int)]
     L.orc_ref64_world_hit.argtypes = [C.POINTER(Sphere), C.c_int, dp, dp, C.c_double, C.c_double, dp]
@@ -178,3 +182,17 @@ def render_mirror32(spheres, n, cam, W, H, spp, depth, seed=0xE7, rows=None, thr
                                    C.byref(seg))
     assert rc == 0
     return rgb, acc, hid, seg.value
+
+
+def render_mirror32_audited(*args, **kw):
+    """render_mirror32 with the sphere screen switched to audit mode (it rejects nothing and is
+    checked against the exact discriminant instead).  Returns (render result, spheres with
+    disc >= 0, how many of them the screen would have dropped, smallest slack in margins)."""
+    lib().orc_mirror32_filter_audit(1)
+    try:
+        out = render_mirror32(*args, **kw)
+        hits, dropped, slack = C.c_uint64(0), C.c_uint64(0), C.c_double(0.0)
+        lib().orc_mirror32_filter_audit_result(C.byref(hits), C.byref(dropped), C.byref(slack))
+    finally:
+        lib().orc_mirror32_filter_audit(0)
+    return out, hits.value, dropped.value, slack.value

@@ -249,3 +249,31 @@ def test_mirror32_tracks_ref64_on_a_wide_scene(oracle):
     assert _psnr(r64[0], r32[0]) >= 40.0
     assert np.mean(r64[2] != r32[2]) < 2e-3
     assert abs(r64[3] - r32[3]) / r64[3] < 5e-3
+
+
+def test_sphere_screen_never_drops_a_true_hit(oracle, book_scene):
+    """The packed screen (n^2 + (2o).c - k >= |o|^2 - margin) that the GPU and its CPU mirror put in
+    front of Sphere.hit (hitrecord.nim:56-63) only ever adds work: with the screen disabled the mirror
+    produces the same sums bit for bit, no sphere with an exact discriminant >= 0 falls below the
+    threshold, and the closest call still has most of the margin left."""
+    cases = []
+    arr, n = book_scene
+    cases.append(("book", arr, n, oracle.book_camera(1.5), 120, 80, 6))
+    a3, n3, _, _ = oracle.random_scene(lambert_below=0.0, metal_below=0.5)
+    cases.append(("metal+glass", a3, n3, oracle.book_camera(1.5), 90, 60, 6))
+    a5, n5, _, _ = oracle.random_scene(half_extent=50)        # 10k spheres, centres out to |c| = 71
+    cases.append(("10k", a5, n5, oracle.book_camera(1.5), 48, 32, 2))
+    am, nm = oracle.mix_of_spheres()                            # hollow glass (negative radius), r = 100 ground
+    cases.append(("mix", am, nm, oracle.book_camera(4 / 3, look_from=(3, 3, 2), look_at=(0, 0, -1), vfov=20.0, aperture=2.0,
+                                                   focus=math.sqrt(27.0)), 80, 60, 16))
+    # camera far from the origin: |o| dominates the margin
+    cases.append(("far camera", arr, n, oracle.book_camera(1.5, look_from=(130, 20, 30), vfov=2.0, focus=133.0), 90, 60, 4))
+    for name, a, k, cam, W, H, spp in cases:
+        plain = oracle.render_mirror32(a, k, cam, W, H, spp, 50)
+        audited, hits, dropped, slack = oracle.render_mirror32_audited(a, k, cam, W, H, spp, 50)
+        assert hits > 1000, name
+        assert dropped == 0, f"{name}: the screen dropped {dropped} of {hits} true hits"
+        assert slack >= 0.5, f"{name}: only {slack:.3f} of the margin left"
+        for x, y in zip(plain[:3], audited[:3]):
+            assert (x == y).all(), name
+        assert plain[3] == audited[3], name
