@@ -432,3 +432,51 @@ def test_smallest_frame_and_depth_one(oracle, book_scene):
         from raytracinginoneweekend_amd import _lib
         with pytest.raises(_lib.RtowError):
             _lib.check(_lib.lib().rtow_render(r._h, 10, 10, 1, 1, 0, None, 5, None, None, None))
+
+
+def test_random_scenes_bit_exact(oracle):
+    """Seeded random worlds the reference's own scenes never visit: 1-60 spheres that overlap, contain
+    one another and the camera, radii from 0.03 to 3 with either sign, ground-like spheres of radius
+    100-3000 (the binary64 path), fuzz up to 1.5 (Metal does not clamp it, hitrecord.nim:37-38),
+    refraction indices 1.05-2.5, random cameras and depths.  GPU == CPU mirror, bit for bit."""
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    R = _R()
+    rng = np.random.default_rng(20241111)
+    W, H = 48, 32
+    with R.Renderer(0) as r:
+        for case in range(24):
+            n = int(rng.integers(1, 61))
+            spread = float(rng.choice([1.0, 4.0, 15.0]))
+            center = rng.normal(0.0, spread, (n, 3))
+            radius = np.exp(rng.uniform(np.log(0.03), np.log(3.0), n)) * rng.choice([1.0, 1.0, 1.0, -1.0], n)
+            kind = rng.integers(0, 3, n)
+            n_big = int(rng.integers(0, 3))
+            for b in range(min(n_big, n)):
+                rad = float(np.exp(rng.uniform(np.log(100.0), np.log(3000.0))))
+                center[b] = (rng.normal(0, 2), -rad - rng.uniform(0.0, 1.0), rng.normal(0, 2))
+                radius[b] = rad
+            albedo = rng.uniform(0.0, 1.0, (n, 3))
+            fuzz = rng.uniform(0.0, 1.5, n) * (rng.uniform(size=n) < 0.7)
+            ir = rng.uniform(1.05, 2.5, n)
+            world = {"center_x": center[:, 0], "center_y": center[:, 1], "center_z": center[:, 2], "radius": radius,
+                     "kind": kind, "albedo": albedo, "fuzz": fuzz, "ir": ir}
+            r.setWorld(world)
+            f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)  # noqa: E731 (the ABI takes binary32)
+            arr, k = oracle.spheres_from_arrays(f32(center), f32(radius), kind, f32(albedo), f32(fuzz), f32(ir))
+            look_from = tuple(rng.normal(0.0, 2.0 * spread + 2.0, 3))
+            look_at = tuple(rng.normal(0.0, 1.0, 3))
+            vfov = float(rng.uniform(10.0, 100.0))
+            aperture = float(rng.choice([0.0, 0.1, 1.0]))
+            focus = float(rng.uniform(0.5, 20.0))
+            r.setCamera(initCamera(point(*look_from), point(*look_at), vec3(0, 1, 0), vfov=vfov, aspectRatio=W / H,
+                                   aperture=aperture, focusDist=focus))
+            cam = oracle.book_camera(W / H, look_from=look_from, look_at=look_at, vfov=vfov, aperture=aperture, focus=focus)
+            depth = int(rng.choice([1, 4, 50]))
+            spp = int(rng.choice([1, 3, 9]))
+            got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+            ref = oracle.render_mirror32(arr, k, cam, W, H, spp, depth)
+            assert (got[2] == ref[2]).all(), f"case {case}: {np.sum(got[2] != ref[2])} primary hit ids differ"
+            assert (got[1] == ref[1]).all(), f"case {case}: {np.sum(got[1] != ref[1])} radiance sums differ"
+            assert (got[0] == ref[0]).all(), f"case {case}: pixels differ"
+            assert r.stats()["ray_segments"] == ref[3], f"case {case}: segment count"
