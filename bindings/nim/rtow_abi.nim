@@ -22,5 +22,8 @@ proc rtow_render*(ctx: RtowCtx, w, h, spp, maxDepth: cint, seed: uint64, rows: p
                   rgbOut: ptr uint8, accumOut: ptr uint64, hitIdOut: ptr int32): cint {.importc, dynlib: rtowLib.}
 proc rtow_render_multi*(ctxs: ptr RtowCtx, nCtx: cint, w, h, spp, maxDepth: cint, seed: uint64, tileRows: cint,
                         rgb: ptr uint8, raySegments: ptr uint64): cint {.importc, dynlib: rtowLib.}
+proc rtow_render_pass*(ctx: RtowCtx, w, h, firstSample, nSamples, maxDepth: cint, seed: uint64, rows: ptr int32,
+                       nRows: cint, rgbDev: pointer): cint {.importc, dynlib: rtowLib.}
+proc rtow_read_image*(ctx: RtowCtx, rgb: ptr uint8, accum: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_format_ppm*(ctx: RtowCtx, binary: cint, dst: cstring, capacity: uint64, length: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_get_stats*(ctx: RtowCtx, stats: ptr RtowStats): cint {.importc, dynlib: rtowLib.}

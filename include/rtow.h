@@ -109,6 +109,22 @@ int rtow_render_async(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uint6
                       const int32_t* rows, int n_rows, void* rgb_dev);
 int rtow_sync(rtow_ctx* ctx);
 
+/* Progressive refinement: one more pass of n_samples samples per pixel on top of what the context's
+ * accumulators hold.  first_sample == 0 starts an image (like rtow_render_async); first_sample > 0
+ * must equal the number of samples accumulated so far for the same w, h, rows and seed
+ * (RTOW_ERR_STATE otherwise).  After every pass the 8-bit image (in rgb_dev, or in the context when
+ * rgb_dev == NULL) is writeColor's (raytracer.nim:22-28) over all first_sample + n_samples samples.
+ * Sample s of a pixel uses the same random stream whichever pass traces it and the sums are
+ * integers, so passes of 100 + 400 samples leave exactly the image of one 500-sample render - a
+ * caller can show or store intermediate frames of the reference's s loop (raytracer.nim:40) at no
+ * cost in the final result.  Asynchronous; statistics describe the pass. */
+int rtow_render_pass(rtow_ctx* ctx, int w, int h, int first_sample, int n_samples, int max_depth,
+                     uint64_t seed, const int32_t* rows, int n_rows, void* rgb_dev);
+
+/* Copy the image of the most recent render out of the context (waits for it): rgb_out n_rows*w*3
+ * bytes, accum_out n_rows*w*3 uint64 fixed-point sums; either may be NULL. */
+int rtow_read_image(rtow_ctx* ctx, uint8_t* rgb_out, uint64_t* accum_out);
+
 /* One frame on several contexts at once - normally one context per GPU of this process, each
  * holding the same scene and camera.  The rows of the image - the outer j loop of render
  * (raytracer.nim:36) - are dealt to the contexts in interleaved tiles of tile_rows rows (tile t goes

@@ -4,6 +4,7 @@
 #include "../../include/rtow.h"
 #include "rtow_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -75,6 +76,10 @@ struct rtow_ctx {
   // last render
   bool pending = false;
   int last_w = 0, last_h = 0, last_spp = 0, last_rows = 0;
+  int samples_done = 0;                       // samples per pixel in the accumulators
+  uint64_t last_seed = 0;
+  std::vector<int32_t> last_row_list;         // rows[] of the render the accumulators belong to (empty = all rows)
+  bool last_row_list_valid = false;
   rtow_stats stats = {};
 };
 
@@ -213,8 +218,10 @@ int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
   return RTOW_OK;
 }
 
+// first_sample > 0: a further pass over the same pixels - the accumulators are kept, the launch traces
+// samples first_sample .. first_sample + spp - 1 and the image is resolved over all of them
 static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed,
-                          const int32_t* rows, int n_rows, void* rgb_dev, bool want_hit_id) {
+                          const int32_t* rows, int n_rows, void* rgb_dev, bool want_hit_id, int first_sample = 0) {
   if (!c) return fail(RTOW_ERR_INVALID, "render: ctx is NULL");
   if (!c->have_scene || !c->have_camera)
     return fail(RTOW_ERR_STATE, "render: call rtow_set_scene and rtow_set_camera first");
@@ -225,6 +232,17 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   if (rows)
     for (int r = 0; r < n_rows; ++r)
       if (rows[r] < 0 || rows[r] >= h) return fail(RTOW_ERR_INVALID, "render: rows[%d] = %d of %d", r, rows[r], h);
+  if (first_sample < 0 || (int64_t)first_sample + spp > 0x7fffffff)
+    return fail(RTOW_ERR_INVALID, "render: samples %d .. %lld", first_sample, (long long)first_sample + spp - 1);
+  if (first_sample > 0) {
+    const bool same_rows = rows ? (c->last_row_list_valid && c->last_row_list.size() == (size_t)n_rows &&
+                                   std::equal(c->last_row_list.begin(), c->last_row_list.end(), rows))
+                                : (c->last_row_list_valid && c->last_row_list.empty());
+    if (c->last_w != w || c->last_h != h || c->last_rows != n_rows || !same_rows || c->samples_done != first_sample ||
+        c->last_seed != seed)
+      return fail(RTOW_ERR_STATE, "render pass: samples %d.. must continue a render of the same image, rows and seed "
+                                  "that stopped at sample %d", first_sample, c->samples_done);
+  }
   const uint64_t n_pixels = (uint64_t)n_rows * (uint64_t)w;
   if (n_pixels >= 0x7fffffffull / 3) return fail(RTOW_ERR_INVALID, "render: %llu pixels in one call", (unsigned long long)n_pixels);
 
@@ -247,7 +265,7 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   p.cmax = c->cmax;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;
-  p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth;
+  p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth; p.sample_base = (uint32_t)first_sample;
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
   p.rows = rows ? (const int32_t*)c->rows.p : nullptr; p.n_rows = n_rows;
   p.chunk_max = 512;
@@ -267,12 +285,12 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemsetAsync(c->counters.p, 0, 16, c->stream));
-  HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
+  if (first_sample == 0) HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
   if (n_pixels) rtow::launch_trace(p, grid, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-  rtow::launch_resolve((const unsigned long long*)c->accum.p, rgb, (uint32_t)(3 * n_pixels), spp, c->stream);
+  rtow::launch_resolve((const unsigned long long*)c->accum.p, rgb, (uint32_t)(3 * n_pixels), first_sample + spp, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(hipMemcpyAsync(c->host_counters, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
@@ -280,6 +298,12 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   c->image_in_workspace = rgb_dev == nullptr;
   c->ppm_bytes = 0;
   c->last_w = w; c->last_h = h; c->last_spp = spp; c->last_rows = n_rows;
+  c->samples_done = first_sample + spp;
+  c->last_seed = seed;
+  if (first_sample == 0) {
+    if (rows) c->last_row_list.assign(rows, rows + n_rows); else c->last_row_list.clear();
+    c->last_row_list_valid = true;
+  }
   return RTOW_OK;
 }
 
@@ -302,6 +326,25 @@ int rtow_sync(rtow_ctx* c) {
 int rtow_render_async(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed,
                       const int32_t* rows, int n_rows, void* rgb_dev) {
   return enqueue_render(c, w, h, spp, max_depth, seed, rows, n_rows, rgb_dev, false);
+}
+
+int rtow_render_pass(rtow_ctx* c, int w, int h, int first_sample, int n_samples, int max_depth, uint64_t seed,
+                     const int32_t* rows, int n_rows, void* rgb_dev) {
+  return enqueue_render(c, w, h, n_samples, max_depth, seed, rows, n_rows, rgb_dev, false, first_sample);
+}
+
+int rtow_read_image(rtow_ctx* c, uint8_t* rgb_out, uint64_t* accum_out) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_read_image: ctx is NULL");
+  if (c->last_w == 0) return fail(RTOW_ERR_STATE, "rtow_read_image: nothing has been rendered on this context");
+  if (rgb_out && !c->image_in_workspace)
+    return fail(RTOW_ERR_STATE, "rtow_read_image: the last render wrote its image to the caller's device buffer");
+  const int rc = rtow_sync(c);
+  if (rc != RTOW_OK) return rc;
+  const size_t n_pixels = (size_t)c->last_rows * (size_t)c->last_w;
+  if (rgb_out && n_pixels) HIP_TRY(hipMemcpy(rgb_out, c->rgb.p, 3 * n_pixels, hipMemcpyDeviceToHost));
+  if (accum_out && n_pixels)
+    HIP_TRY(hipMemcpy(accum_out, c->accum.p, sizeof(uint64_t) * 3 * n_pixels, hipMemcpyDeviceToHost));
+  return RTOW_OK;
 }
 
 int rtow_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed, const int32_t* rows,

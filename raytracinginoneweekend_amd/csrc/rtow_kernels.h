@@ -20,7 +20,8 @@ struct TraceParams {
   const BigSphere* big;      // spheres intersected in binary64
   int n_big;
   const SphereShade* shade;  // one record per list entry
-  int W, H, spp, max_depth;
+  int W, H, spp, max_depth;  // spp: samples per pixel traced by THIS launch
+  uint32_t sample_base;      // index of its first sample (progressive passes continue a pixel's streams)
   uint32_t seed_lo, seed_hi;
   const int32_t* rows;       // image rows to render (0 = top), or nullptr for 0..n_rows-1
   int n_rows;

@@ -357,12 +357,12 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
         int ci = (int)i_base - (int)dp;
         while (ci < 0) { ci += P.W; --r; }
         const int y = P.rows ? P.rows[r] : (int)r;
-        g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample);
+        g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + P.sample_base);
         camera_ray(P.cam, ci, P.H - 1 - y, P.W, P.H, g, o, d);
         tr = tg = tb = 1.0f;
         depth = P.max_depth;
         prev = -1;
-        first_sample = (sample == 0);
+        first_sample = (sample + P.sample_base == 0u);
         alive = true;
       }
       e_next += min(cnt, avail);

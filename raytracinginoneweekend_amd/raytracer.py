@@ -95,6 +95,25 @@ class Renderer:
         _lib.check(self._lib.rtow_render_async(self._h, width, height, samplesPerPixel, maxDepth, seed,
                                                rows_p, n_rows, rgb_dev))
 
+    def renderPass(self, width, height, firstSample, nSamples, maxDepth, seed=RENDER_SEED, rows=None, rgb_dev=None):
+        """Progressive refinement: add samples firstSample .. firstSample+nSamples-1 of every pixel to the
+        image this context holds (firstSample = 0 starts one).  Asynchronous."""
+        keep, n_rows, rows_p = self._rows(rows, height)
+        if rows is not None and n_rows == 0:
+            rows_p = np.zeros(1, np.int32).ctypes.data
+        _lib.check(self._lib.rtow_render_pass(self._h, width, height, firstSample, nSamples, maxDepth, seed,
+                                              rows_p, n_rows, rgb_dev))
+        self._last_shape = (n_rows, width)
+
+    def readImage(self, want_accum=False):
+        """(rgb uint8 [n_rows, w, 3], accum uint64 | None) of the last renderPass on this context."""
+        n_rows, width = self._last_shape
+        rgb = np.empty((n_rows, width, 3), np.uint8)
+        acc = np.empty((n_rows, width, 3), np.uint64) if want_accum else None
+        _lib.check(self._lib.rtow_read_image(self._h, rgb.ctypes.data if rgb.size else None,
+                                             acc.ctypes.data if acc is not None and acc.size else None))
+        return rgb, acc
+
     def sync(self):
         _lib.check(self._lib.rtow_sync(self._h))
 

@@ -480,3 +480,40 @@ def test_random_scenes_bit_exact(oracle):
             assert (got[1] == ref[1]).all(), f"case {case}: {np.sum(got[1] != ref[1])} radiance sums differ"
             assert (got[0] == ref[0]).all(), f"case {case}: pixels differ"
             assert r.stats()["ray_segments"] == ref[3], f"case {case}: segment count"
+
+
+def test_progressive_passes_reach_the_single_render_image(gpu_renderer):
+    """rtow_render_pass: samples added in passes (3 + 1 + 60 + 436) leave the sums, the pixels, the PPM text
+    and the segment total of one 500-sample render; intermediate images are those of renders that
+    stop there; a pass that does not continue the image is refused."""
+    from raytracinginoneweekend_amd import _lib
+    R = _R()
+    W, H = 96, 64
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    for rows in (None, [60, 3, 4, 5]):
+        whole = gpu_renderer.renderRows(W, H, 500, 50, rows=rows, want_accum=True)
+        seg_whole = gpu_renderer.stats()["ray_segments"]
+        text_whole = gpu_renderer.ppm()
+        done, seg = 0, 0
+        for k in (3, 1, 60, 436):
+            gpu_renderer.renderPass(W, H, done, k, 50, rows=rows)
+            done += k
+            rgb, acc = gpu_renderer.readImage(want_accum=True)
+            seg += gpu_renderer.stats()["ray_segments"]
+            if done == 4:
+                upto = gpu_renderer.renderRows(W, H, 4, 50, rows=rows, want_accum=True)
+                assert (upto[0] == rgb).all() and (upto[1] == acc).all()
+                # renderRows started a new image: replay the passes so far
+                gpu_renderer.renderPass(W, H, 0, 4, 50, rows=rows)
+        assert (acc == whole[1]).all() and (rgb == whole[0]).all() and seg == seg_whole
+        assert gpu_renderer.ppm() == text_whole
+    for bad in ((W, H, 499, 1), (W, H, 501, 1), (W + 1, H, 500, 1)):   # gap, overlap-free but wrong count, other size
+        with pytest.raises(_lib.RtowError) as e:
+            gpu_renderer.renderPass(bad[0], bad[1], bad[2], bad[3], 50, rows=[60, 3, 4, 5])
+        assert e.value.status == -3
+    with pytest.raises(_lib.RtowError):
+        gpu_renderer.renderPass(W, H, 500, 1, 50, rows=[60, 3, 4, 6])      # other rows
+    with pytest.raises(_lib.RtowError):
+        gpu_renderer.renderPass(W, H, 500, 1, 50, seed=1, rows=[60, 3, 4, 5])  # other seed
+    gpu_renderer.renderPass(W, H, 500, 12, 50, rows=[60, 3, 4, 5])              # a proper continuation still works
+    assert (gpu_renderer.readImage()[0] == gpu_renderer.renderRows(W, H, 512, 50, rows=[60, 3, 4, 5])[0]).all()
