@@ -10,7 +10,7 @@ read-back.  Steps are kept two deep in flight (two contexts, each with its own s
 buffers, used in turn): the tail of a frame overlaps the start of the next one.  All K steps
 start and complete inside the timed region; `latency_ms_per_step` is one step on its own.  With N > 1 (launched by torch.distributed.run, one process per GPU) the same frame
 is sharded by interleaved row tiles and each step ends with the RCCL gather of the 8-bit rows,
-so total work is fixed ("strong" scaling, BASELINE config 4).
+so total work is fixed ("strong" scaling).
 
 Prints ONE JSON line on rank 0.  value = ray segments (world.hit queries) of all ranks / wall
 seconds / 1e6.  roofline: algorithmic FLOP (18 per ray-sphere test, 18*N+65 per segment) over

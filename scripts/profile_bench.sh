@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 passes for the round-1 profile; run on the GPU box from the repo root.
+# rocprofv3 kernel trace + counter passes of bench.py; run on the GPU box from the repo root.
 set -e
 export TMPDIR=/tmp
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_r01d
+OUT=$REPO/gpurun_out/prof_bench
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.err
