@@ -225,10 +225,12 @@ static __device__ __forceinline__ void wave_flush(unsigned long long* accum, boo
 
 template <bool K_LDS>
 __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const TraceParams P) {
-  // LDS: candidate stacks [4 waves][kCandDepth][64] first, then (K_LDS) -k per sphere
+  // LDS: candidate stacks [4 waves][kCandDepth][64], path pools [4 waves][kPoolFields][64], then
+  // (K_LDS) -k per sphere
   extern __shared__ f4v lds_raw[];
   uint32_t* const stacks = (uint32_t*)lds_raw;
-  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * kCandDepth * 64 / 4;
+  uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandDepth * 64 + (threadIdx.x >> 6) * (kPoolFields * 64);
+  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64 / 4;
   const uint32_t lane = threadIdx.x & 63u;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
   CandStack cand;
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
   cand.n = 0;
   if (K_LDS) {
     const int n4 = P.n_geom_pad / 4 + 1;
-    f4v* const dst = lds_raw + (kTraceThreads / 64) * kCandDepth * 64 / 4;
+    f4v* const dst = lds_raw + (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64 / 4;
     for (int i = threadIdx.x; i < n4; i += kTraceThreads) dst[i] = ((const f4v*)P.geom_nk)[i];
     __syncthreads();
   }
@@ -245,6 +247,7 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
   // pixel-major order (all samples of a pixel, then the next pixel of the row list).
   uint32_t e_next = 0, e_end = 0;     // offsets inside the chunk
   unsigned long long seen = 0;        // first path of this wave's previous chunk
+  uint32_t pool_n = 0, pool_head = 0; // camera rays generated into the pool / already handed to lanes
   uint32_t p_base = 0, s_base = 0;    // pixel (index in the row list's image) and sample of the chunk's first path
   uint32_t r_base = 0, i_base = 0;    // row (in the row list) and column of that pixel
   bool exhausted = false;
@@ -275,7 +278,8 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
     for (;;) {
       const uint64_t need = __ballot(!alive);
       if (need == 0) break;
-      if (e_next >= e_end) {
+      if (pool_head >= pool_n) {
+       if (e_next >= e_end) {
         if (exhausted) break;
         // guided self-scheduling: a quarter of an even share of what was left when this wave
         // last looked, clamped to [chunk_min, chunk_max] and rounded down to whole wavefronts
@@ -331,41 +335,69 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
         i_base = p_base - r_base * (uint32_t)P.W;
         e_next = 0;
         e_end = left < want ? (uint32_t)left : want;
+       }
+        // ---- generate: the next (up to) 64 paths of the chunk, one per lane, ALL lanes at work
+        const uint32_t n_gen = min(64u, e_end - e_next);
+        const bool gen = lane < n_gen;
+        // (pixel, sample) of lane's path: e counts samples from the first sample of the chunk's
+        // first pixel.  With spp >= chunk_max it overflows spp at most once.
+        const uint32_t e = s_base + e_next + (gen ? lane : 0u);
+        uint32_t dp, sample;
+        if ((uint32_t)P.spp >= P.chunk_max) {
+          dp = e >= (uint32_t)P.spp ? 1u : 0u;
+          sample = e - (dp ? (uint32_t)P.spp : 0u);
+        } else {
+          // e < 2 * chunk_max + spp and spp < chunk_max here: exact (2^32 / 1 does not fit inv_spp)
+          dp = P.spp == 1 ? e : __umulhi(e, P.inv_spp);
+          sample = e - dp * (uint32_t)P.spp;
+        }
+        if (gen) {
+          uint32_t r = r_base;
+          int ci = (int)i_base - (int)dp;
+          while (ci < 0) { ci += P.W; --r; }
+          const int y = P.rows ? P.rows[r] : (int)r;
+          Stream g2 = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + P.sample_base);
+          f3 o2, d2;
+          camera_ray(P.cam, ci, P.H - 1 - y, P.W, P.H, g2, o2, d2);
+          pool[0 * 64 + lane] = __float_as_uint(o2.x); pool[1 * 64 + lane] = __float_as_uint(o2.y);
+          pool[2 * 64 + lane] = __float_as_uint(o2.z); pool[3 * 64 + lane] = __float_as_uint(d2.x);
+          pool[4 * 64 + lane] = __float_as_uint(d2.y); pool[5 * 64 + lane] = __float_as_uint(d2.z);
+          pool[6 * 64 + lane] = g2.x0; pool[7 * 64 + lane] = g2.key1;
+          // local pixel index (< 2^31 / 3); top bit: sample 0 of the pixel (it records the hit-id plane)
+          pool[8 * 64 + lane] = (p_base - dp) | ((sample + P.sample_base == 0u) ? 0x80000000u : 0u);
+        }
+        e_next += n_gen;
+        pool_n = n_gen;
+        pool_head = 0;
+        // the pool is written and read by different lanes of this one wave: LDS serves a wave's
+        // requests in order, the compiler only has to keep them in order too
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      const uint32_t avail = e_end - e_next;
+      // ---- hand pooled paths to the idle lanes
+      const uint32_t avail = pool_n - pool_head;
       const uint32_t rank = lanes_below(need);
       const uint32_t cnt = (uint32_t)__popcll(need);
       const bool take = !alive && rank < avail;
-      // (pixel, sample) of the path this lane would take: e counts samples from the first sample
-      // of the chunk's first pixel.  With spp >= chunk_max it overflows spp at most once.
-      const uint32_t e = s_base + e_next + (take ? rank : 0u);
-      uint32_t dp, sample;
-      if ((uint32_t)P.spp >= P.chunk_max) {
-        dp = e >= (uint32_t)P.spp ? 1u : 0u;
-        sample = e - (dp ? (uint32_t)P.spp : 0u);
-      } else {
-        // e < 2 * chunk_max + spp and spp < chunk_max here: exact (2^32 / 1 does not fit inv_spp)
-        dp = P.spp == 1 ? e : __umulhi(e, P.inv_spp);
-        sample = e - dp * (uint32_t)P.spp;
-      }
-      const uint32_t pix_local = p_base - dp;
+      const uint32_t entry = take ? pool_head + rank : 0u;
+      const uint32_t pix_word = pool[8 * 64 + entry];
+      const uint32_t pix_local = pix_word & 0x7fffffffu;
       // a lane that moves on to another pixel hands its sums over first
       wave_flush(P.accum, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
       if (take) {
         if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
-        uint32_t r = r_base;
-        int ci = (int)i_base - (int)dp;
-        while (ci < 0) { ci += P.W; --r; }
-        const int y = P.rows ? P.rows[r] : (int)r;
-        g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + P.sample_base);
-        camera_ray(P.cam, ci, P.H - 1 - y, P.W, P.H, g, o, d);
+        o.x = __uint_as_float(pool[0 * 64 + entry]); o.y = __uint_as_float(pool[1 * 64 + entry]);
+        o.z = __uint_as_float(pool[2 * 64 + entry]); d.x = __uint_as_float(pool[3 * 64 + entry]);
+        d.y = __uint_as_float(pool[4 * 64 + entry]); d.z = __uint_as_float(pool[5 * 64 + entry]);
+        g.x0 = pool[6 * 64 + entry]; g.key1 = pool[7 * 64 + entry];
         tr = tg = tb = 1.0f;
         depth = P.max_depth;
         prev = -1;
-        first_sample = (sample + P.sample_base == 0u);
+        first_sample = (pix_word >> 31) != 0u;
         alive = true;
       }
-      e_next += min(cnt, avail);
+      pool_head += min(cnt, avail);
     }
     if (__ballot(alive) == 0) break;
     RTOW_COUNT(4, __popcll(__ballot(alive)));
@@ -449,7 +481,7 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
   if (i < n_channels) rgb[i] = (uint8_t)quantise_fix(accum[i], spp);
 }
 
-static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * kCandDepth * 64; }
+static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64; }
 static size_t k_lds_bytes(int n_geom_pad) { return stack_lds_bytes() + sizeof(float) * (size_t)(n_geom_pad + 4); }
 
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream) {
