@@ -124,8 +124,9 @@ static __device__ __forceinline__ void cand_push(CandStack& c, bool pass, int j)
 }
 
 static __device__ __forceinline__ void cand_drain(CandStack& c, const float4* __restrict__ exact, f3 o, f3 u,
-                                                  float tmin, int prev, float& best, int& id) {
+                                                  float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
   for (uint32_t i = 0; __ballot(i < c.n) != 0; ++i) {
+    RTOW_COUNT(10, 1);
     if (i < c.n) {
       const int j = (int)c.slot[i * 64u];
       const float4 sp = exact[j];   // (cx, cy, cz, r^2)
@@ -147,9 +148,10 @@ static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, 
   const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, nk.xy, r);
   const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
+  RTOW_COUNT(9, __ballot(mx >= r.threshold) != 0 ? 1 : 0);
   if (mx >= r.threshold) {
     RTOW_COUNT(0, 1);
-    if (__ballot(cand.n > (uint32_t)(kCandDepth - 4)) != 0) cand_drain(cand, exact, o, u, tmin, prev, best, id);
+    if (__ballot(cand.n > (uint32_t)(kCandDepth - 4)) != 0) cand_drain(cand, exact, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     cand_push(cand, f0.x >= r.threshold, j);
     cand_push(cand, f0.y >= r.threshold, j + 1);
     cand_push(cand, f1.x >= r.threshold, j + 2);
@@ -190,7 +192,7 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, const float4*
     if (K_LDS) { ka = nk[2]; nk += 2; } else kb = f4v{-gb.s6, -gb.s7, -gb.se, -gb.sf};
     group_test(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
   }
-  cand_drain(cand, exact, o, u, tmin, prev, best, id);
+  cand_drain(cand, exact, o, u, tmin, prev, best, id RTOW_PROF_ARG);
 }
 
 static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -366,6 +368,7 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
           // local pixel index (< 2^31 / 3); top bit: sample 0 of the pixel (it records the hit-id plane)
           pool[8 * 64 + lane] = (p_base - dp) | ((sample + P.sample_base == 0u) ? 0x80000000u : 0u);
         }
+        RTOW_COUNT(14, 1);
         e_next += n_gen;
         pool_n = n_gen;
         pool_head = 0;
@@ -420,6 +423,9 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
     const unsigned long long t_scan0 = RTOW_CLOCK();
     if (alive) scan_regular<K_LDS>(geom, P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     const unsigned long long t_scan1 = RTOW_CLOCK();
+#ifdef RTOW_PROFILE_COUNTERS
+    uint32_t shade_draws = 0;
+#endif
     if (alive) {
       if (P.hit_id && first_sample && depth == P.max_depth) P.hit_id[accpix] = id;
 
@@ -431,7 +437,13 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       } else {
         const SphereShade sh = P.shade[id];
         f3 dn;
+#ifdef RTOW_PROFILE_COUNTERS
+        const uint32_t x0_before = g.x0;
+#endif
         const bool scattered = shade_hit(sh, o, u, best, g, dn, tr, tg, tb);
+#ifdef RTOW_PROFILE_COUNTERS
+        shade_draws = (g.x0 - x0_before) * 0x144cbc89u;
+#endif
         d = dn;
         prev = id;
         --depth;
@@ -443,6 +455,13 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
       }
     }
     RTOW_COUNT(3, 1);
+#ifdef RTOW_PROFILE_COUNTERS
+    {
+      uint32_t m = shade_draws;
+      for (int off = 32; off > 0; off >>= 1) { const uint32_t t_ = __shfl_xor(m, off, 64); m = t_ > m ? t_ : m; }
+      RTOW_COUNT(11, m / 3u);   // rejection-loop trips of the slowest lane
+    }
+#endif
 #ifdef RTOW_PROFILE_TIMELINE
     ++iters_;
     if (lane == 0 && wave_id < 16384 && exhausted) {

@@ -18,3 +18,5 @@ print(f"segments {st['ray_segments']}  wave iterations {wi}  lane iterations {li
 print(f"per wave iteration: group slow-path entries {g/wi:.2f} of {(len(scene)+7)//8*2}, candidate spheres (wave level) {cw/wi:.2f}, candidate lanes {cl/wi:.2f} (per lane {cl/li:.3f})")
 tot = buf[5] + buf[6] + buf[7] + buf[8]
 print(f"wave-cycle split: refill {buf[5]/tot:.3f}  normalise+big {buf[6]/tot:.3f}  scan {buf[7]/tot:.3f}  shade {buf[8]/tot:.3f}  (cycles per wave iteration {tot/wi:.0f})")
+print(f"per wave iteration: groups with a survivor in any lane {buf[9]/wi:.2f}, drain rounds {buf[10]/wi:.2f}, "
+      f"unit-ball loop trips (slowest lane) {buf[11]/wi:.2f}, pool batches {buf[14]/wi:.3f}")
