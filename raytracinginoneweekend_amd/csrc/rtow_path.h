@@ -67,8 +67,9 @@ RTOW_HD uint32_t draw_u32(Stream& g) {
 
 // uniform in [0,1), 24 random bits: rand(1.0)
 RTOW_HD float draw(Stream& g) { return (float)(draw_u32(g) >> 8) * (1.0f / 16777216.0f); }
-// rand(-1.0 .. 1.0) = rand(2.0) - 1.0; exact in binary32
-RTOW_HD float draw_pm1(Stream& g) { return fmaf(2.0f, draw(g), -1.0f); }
+// rand(-1.0 .. 1.0) = rand(2.0) - 1.0 = (k - 2^23) / 2^23 for the 24-bit integer k: every step is
+// exact in binary32, so one fused operation on k gives the same bits as 2 * draw - 1
+RTOW_HD float draw_pm1(Stream& g) { return fmaf((float)(draw_u32(g) >> 8), 1.0f / 8388608.0f, -1.0f); }
 
 // randomInUnitSphere (basetypes.nim:114-118): x, y, z drawn in order, rejected while |p|^2 >= 1
 RTOW_HD f3 unit_ball(Stream& g, float& l2) {
