@@ -19,7 +19,7 @@
  *     cancels catastrophically in binary32; their roots are then taken in binary32 as
  *     q = -(b + sign(b) sqrt(disc)), {q, c/q}; all other spheres use binary32 only;
  *   - every binary32 sphere is first screened by a cheaper evaluation of its discriminant,
- *     n^2 + ((2o).c - k) >= |o|^2 - 2^-19 (|o| + cmax)^2 with n = c.u - o.u and k = |c|^2 - r^2,
+ *     n^2 + ((2o).c - k) >= |o|^2 - 2^-18 (|o|^2 + cmax^2) with n = c.u - o.u and k = |c|^2 - r^2,
  *     and only spheres that pass get the exact test below (the screen is there because the GPU
  *     evaluates it for two spheres per packed instruction; its margin is several times the
  *     rounding error of both evaluations, so in practice it only removes non-candidates);
@@ -60,7 +60,7 @@ typedef struct {
 } cam32;
 
 #define BIG_RADIUS 100.0f
-#define FILTER_MARGIN (1.0f / 524288.0f) /* 2^-19 */
+#define FILTER_MARGIN (1.0f / 262144.0f) /* 2^-18 */
 #define FIX_ONE 1073741824.0f /* 2^30 */
 #define RADIANCE_CLAMP 3.5f
 
@@ -153,12 +153,11 @@ static int closest_hit(const sph32* w, int n, float cmax, f3 o, f3 u, float tmin
   float best = INFINITY;
   int id = -1;
   /* per-ray operands of the filter that screens every binary32 sphere:
-   *   n^2 + (2o).c - k >= |o|^2 - margin,  n = c.u - o.u,  margin = 2^-19 (|o| + cmax)^2 */
+   *   n^2 + (2o).c - k >= |o|^2 - margin,  n = c.u - o.u,  margin = 2^-18 (|o|^2 + cmax^2) */
   const float nou = -dot3(o, u);
   const float ox2 = 2.0f * o.x, oy2 = 2.0f * o.y, oz2 = 2.0f * o.z;
   const float oo = dot3(o, o);
-  const float reach = sqrtf(oo) + cmax;
-  const float margin_abs = FILTER_MARGIN * (reach * reach);
+  const float margin_abs = FILTER_MARGIN * (oo + cmax * cmax);
   const float threshold = oo - margin_abs;
   const int audit = atomic_load(&g_audit_mode);
   for (int j = 0; j < n; ++j) {

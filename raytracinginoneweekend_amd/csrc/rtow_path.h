@@ -132,12 +132,12 @@ RTOW_HD bool regular_candidate(float b, float disc, float tmin, bool self, float
 // ------------------------------------------------------------------ the scan's filter
 // Every sphere is first screened with  n^2 + (2o).c - k >= |o|^2 - margin,  n = c.u - o.u,
 // k = |c|^2 - r^2 (binary64 on the host, rounded once), which is algebraically
-// disc >= -margin.  margin = 2^-19 (|o| + cmax)^2 with cmax = max(|c| + |r|) over the table: about
-// 32 ulps of the largest intermediate, several times the rounding error the two evaluations can
-// accumulate, and a few percent of r^2 for the scenes this renderer is used on.  Spheres that
-// pass get the exact test; the screen is part of the arithmetic contract (the CPU mirror
-// evaluates it with the same operations in the same order).
-constexpr float kFilterMargin = 1.0f / 524288.0f;  // 2^-19
+// disc >= -margin.  margin = 2^-18 (|o|^2 + cmax^2) >= 2^-19 (|o| + cmax)^2 with cmax = max(|c| + |r|)
+// over the table: at least 32 ulps of the largest intermediate, several times the rounding error
+// the two evaluations can accumulate, and a few percent of r^2 for the scenes this renderer is
+// used on.  Spheres that pass get the exact test; the screen is part of the arithmetic contract
+// (the CPU mirror evaluates it with the same operations in the same order).
+constexpr float kFilterMargin = 1.0f / 262144.0f;  // 2^-18
 
 struct FilterRay {
   float nou;             // -(o.u)
@@ -150,8 +150,7 @@ RTOW_HD FilterRay filter_ray(f3 o, f3 u, float cmax) {
   f.nou = -dot3(o, u);
   f.ox2 = 2.0f * o.x; f.oy2 = 2.0f * o.y; f.oz2 = 2.0f * o.z;
   const float oo = dot3(o, o);
-  const float s = sqrtf(oo) + cmax;
-  f.threshold = oo - kFilterMargin * (s * s);
+  f.threshold = oo - kFilterMargin * (oo + cmax * cmax);
   return f;
 }
 
