@@ -185,6 +185,13 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     s.cx = cx[j]; s.cy = cy[j]; s.cz = cz[j]; s.inv_r = 1.0f / r;
     s.ar = albedo[3 * j]; s.ag = albedo[3 * j + 1]; s.ab = albedo[3 * j + 2]; s.fuzz = fuzz[j];
     s.kind = kind[j]; s.ir = ir[j]; s.inv_ir = 1.0f / ir[j]; s.pad_ = 0.f;
+    if (kind[j] == RTOW_DIELECTRIC) {
+      // a dielectric has no albedo (hitrecord.nim:109): its slots carry Schlick's r0^2 (hitrecord.nim:103-104)
+      // for the two refraction ratios a hit can see, evaluated here exactly as the kernel used to
+      s.ar = rtow::schlick_r0(s.inv_ir);   // front face: ratio = 1 / ir
+      s.ag = rtow::schlick_r0(s.ir);       // back face:  ratio = ir
+      s.ab = 0.f;
+    }
   }
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));

@@ -198,9 +198,16 @@ RTOW_HD void offer(bool valid, float t, int j, float& best, int& id) {
 }
 
 // ------------------------------------------------------------------ shading
+// r0 of Schlick's approximation (hitrecord.nim:103-104), squared, in binary32 as the CPU mirror
+// evaluates it per hit; the device reads it from the sphere's record instead
+RTOW_HD float schlick_r0(float ratio) {
+  const float r0 = (1.0f - ratio) / (1.0f + ratio);
+  return r0 * r0;
+}
+
 struct SphereShade {   // 48 bytes, fetched by hit index only
   float cx, cy, cz, inv_r;
-  float ar, ag, ab, fuzz;
+  float ar, ag, ab, fuzz;   // albedo; for a dielectric (ar, ag) = schlick_r0(1/ir), schlick_r0(ir)
   int32_t kind; float ir, inv_ir, pad_;
 };
 
@@ -230,8 +237,7 @@ RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3
     const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
     bool reflect_it = ratio * sin_t > 1.0f;
     if (!reflect_it) {  // the draw happens only when refraction is possible
-      float r0 = (1.0f - ratio) / (1.0f + ratio);
-      r0 = r0 * r0;
+      const float r0 = front ? s.ar : s.ag;   // schlick_r0(ratio), precomputed per sphere
       const float x = 1.0f - cos_t;
       const float x2 = x * x;
       const float x5 = x2 * x2 * x;
