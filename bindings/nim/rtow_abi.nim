@@ -26,4 +26,5 @@ proc rtow_render_pass*(ctx: RtowCtx, w, h, firstSample, nSamples, maxDepth: cint
                        nRows: cint, rgbDev: pointer): cint {.importc, dynlib: rtowLib.}
 proc rtow_read_image*(ctx: RtowCtx, rgb: ptr uint8, accum: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_format_ppm*(ctx: RtowCtx, binary: cint, dst: cstring, capacity: uint64, length: ptr uint64): cint {.importc, dynlib: rtowLib.}
+proc rtow_selftest_arithmetic*(ctx: RtowCtx, mismatches: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_get_stats*(ctx: RtowCtx, stats: ptr RtowStats): cint {.importc, dynlib: rtowLib.}

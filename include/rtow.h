@@ -147,6 +147,13 @@ int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, i
  * rtow_render_multi with rgb_dev == NULL); waits for it if it is still running. */
 int rtow_format_ppm(rtow_ctx* ctx, int binary, char* out, uint64_t capacity, uint64_t* length);
 
+/* Self test of the device arithmetic: the kernels take square roots and reciprocals with short
+ * correctly-rounded sequences of their own; this runs every one of the 2^32 binary32 bit patterns
+ * through them and through the compiler's sqrtf(x) and 1.0f / x on the GPU and returns how many
+ * results differ (mismatches[0] sqrt, [1] reciprocal; both must be 0 - the CPU restatement the
+ * renderer is checked against uses the C library's correctly rounded operations).  About 0.1 s. */
+int rtow_selftest_arithmetic(rtow_ctx* ctx, uint64_t mismatches[2]);
+
 /* Statistics of the last completed render (call after rtow_render or rtow_sync). */
 int rtow_get_stats(rtow_ctx* ctx, rtow_stats* out);
 

@@ -461,6 +461,19 @@ int rtow_format_ppm(rtow_ctx* c, int binary, char* out, uint64_t capacity, uint6
   return RTOW_OK;
 }
 
+int rtow_selftest_arithmetic(rtow_ctx* c, uint64_t mismatches[2]) {
+  if (!c || !mismatches) return fail(RTOW_ERR_INVALID, "rtow_selftest_arithmetic: NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->pending) { const int rc = rtow_sync(c); if (rc != RTOW_OK) return rc; }
+  HIP_TRY(c->counters.reserve(16));
+  HIP_TRY(hipMemsetAsync(c->counters.p, 0, 16, c->stream));
+  rtow::launch_arithmetic_selftest((unsigned long long*)c->counters.p, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(mismatches, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOW_OK;
+}
+
 int rtow_get_stats(rtow_ctx* c, rtow_stats* out) {
   if (!c || !out) return fail(RTOW_ERR_INVALID, "rtow_get_stats: NULL argument");
   *out = c->stats;

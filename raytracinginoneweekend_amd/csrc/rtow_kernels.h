@@ -43,6 +43,8 @@ void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);
 int trace_blocks_per_cu(int n_geom_pad);
+// mismatches[0..1] += inputs (of all 2^32) where the kernels' sqrt / reciprocal differ from sqrtf / 1.0f/x
+void launch_arithmetic_selftest(unsigned long long* mismatches, hipStream_t stream);
 
 // P3 text of an 8-bit image, one "r g b\n" line per pixel (raytracer.nim:28), formatted on the device.
 constexpr int kPpmBlock = 256;   // pixels per workgroup

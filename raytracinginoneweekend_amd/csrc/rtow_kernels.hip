@@ -627,6 +627,25 @@ void launch_ppm_text(const uint8_t* rgb, uint32_t n_pixels, const unsigned long 
                      n_pixels, block_off, text);
 }
 
+// ------------------------------------------------------------------ self test of rt_sqrt / rt_rcp
+// every binary32 bit pattern against the compiler's correctly rounded sqrtf(x) and 1.0f / x
+__global__ void __launch_bounds__(256) arithmetic_selftest_kernel(unsigned long long* mismatches) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned int bad_sqrt = 0, bad_rcp = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+    const float x = __uint_as_float((uint32_t)i);
+    const float a = rt_sqrt(x), b = sqrtf(x), c = rt_rcp(x), d = 1.0f / x;
+    bad_sqrt += !(__float_as_uint(a) == __float_as_uint(b) || (a != a && b != b));
+    bad_rcp += !(__float_as_uint(c) == __float_as_uint(d) || (c != c && d != d));
+  }
+  if (bad_sqrt) atomicAdd(&mismatches[0], (unsigned long long)bad_sqrt);
+  if (bad_rcp) atomicAdd(&mismatches[1], (unsigned long long)bad_rcp);
+}
+
+void launch_arithmetic_selftest(unsigned long long* mismatches, hipStream_t stream) {
+  hipLaunchKernelGGL(arithmetic_selftest_kernel, dim3(256 * 8), dim3(256), 0, stream, mismatches);
+}
+
 #ifdef RTOW_PROFILE_COUNTERS
 extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -2;

@@ -33,6 +33,34 @@ struct f3 { float x, y, z; };
 
 RTOW_HD float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 
+// ------------------------------------------------------------------ sqrt and reciprocal
+// Correctly rounded, like sqrtf(x) and 1.0f / x, whose results they reproduce for EVERY input (the
+// library's self test runs all 2^32 bit patterns through both).  The compiler's own sequences
+// spend a third of their instructions on scaling subnormal and huge operands; these keep the
+// hardware estimate plus the rounding correction and send the operands that need scaling - which
+// this renderer only meets by accident - to the compiler's version.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RTOW_COMPILER_SQRT_RCP)
+static __device__ __forceinline__ float rt_sqrt(float x) {
+  // the estimate flushes subnormals (of either sign) to zero and the residuals of tiny operands underflow
+  if (__builtin_expect(fabsf(x) < 0x1p-96f && x != 0.0f, 0)) return sqrtf(x);
+  float s = __builtin_amdgcn_sqrtf(x);                                 // within 1 ulp
+  const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_dn = fmaf(-s_dn, s, x), r_up = fmaf(-s_up, s, x);      // exact signs of x - s_dn*s and x - s_up*s
+  s = r_dn <= 0.0f ? s_dn : s;
+  s = r_up > 0.0f ? s_up : s;
+  return s;
+}
+static __device__ __forceinline__ float rt_rcp(float x) {
+  const float ax = fabsf(x);
+  if (__builtin_expect(!(ax >= 0x1p-126f && ax <= 0x1p126f), 0)) return 1.0f / x;  // subnormal operand or result, 0, inf, NaN
+  const float y = __builtin_amdgcn_rcpf(x);                                        // within 1 ulp
+  return fmaf(fmaf(-x, y, 1.0f), y, y);                                            // one Newton step lands on the rounded quotient
+}
+#else
+RTOW_HD float rt_sqrt(float x) { return sqrtf(x); }
+RTOW_HD float rt_rcp(float x) { return 1.0f / x; }
+#endif
+
 // ------------------------------------------------------------------ random stream of a path
 // Draw k of path (pixel, sample) is hash(key0 + k*golden) with key1 folded in half way:
 // a pure function of (seed, pixel, sample, k).  It stands in for the reference's global
@@ -108,8 +136,8 @@ RTOW_HD void camera_ray(const CameraParams& cam, int i, int j, int W, int H, Str
 
 // Unit direction and the reference's t_min expressed as a distance.
 RTOW_HD void segment_begin(f3 d, f3& u, float& tmin) {
-  const float len = sqrtf(dot3(d, d));
-  const float il = 1.0f / len;
+  const float len = rt_sqrt(dot3(d, d));
+  const float il = rt_rcp(len);
   u.x = d.x * il; u.y = d.y * il; u.z = d.z * il;
   tmin = kTMin * len;
 }
@@ -122,7 +150,7 @@ RTOW_HD void segment_begin(f3 d, f3& u, float& tmin) {
 RTOW_HD bool regular_candidate(float b, float disc, float tmin, bool self, float& t) {
   // written with selects instead of branches: few lanes ever get here and the GPU runs both
   // sides of a branch anyway
-  const float s = sqrtf(disc);
+  const float s = rt_sqrt(disc);
   const float t_near = -b - s, t_far = -b + s;
   t = t_near < tmin ? t_far : t_near;
   t = self ? -2.0f * b : t;
@@ -180,7 +208,7 @@ RTOW_HD bool big_candidate(f3 o, f3 u, const BigSphere& s, float tmin, bool self
   const double c = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -s.rr)));
   const double disc = fma(hb, hb, -c);
   const float bf = (float)hb, cf = (float)c;
-  const float sq = sqrtf((float)disc);
+  const float sq = rt_sqrt((float)disc);
   const float q = bf < 0.0f ? sq - bf : -bf - sq;
   const float other = cf / q;
   const float t_near = fminf(q, other), t_far = fmaxf(q, other);
@@ -234,7 +262,7 @@ RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3
     const float ratio = front ? s.inv_ir : s.ir;
     const float dn = dot3(u, n);
     const float cos_t = fminf(-dn, 1.0f);
-    const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+    const float sin_t = rt_sqrt(fmaf(-cos_t, cos_t, 1.0f));
     bool reflect_it = ratio * sin_t > 1.0f;
     if (!reflect_it) {  // the draw happens only when refraction is possible
       const float r0 = front ? s.ar : s.ag;   // schlick_r0(ratio), precomputed per sphere
@@ -250,14 +278,14 @@ RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3
     } else {           // refract, basetypes.nim:104-108
       const f3 perp = {ratio * fmaf(cos_t, n.x, u.x), ratio * fmaf(cos_t, n.y, u.y),
                        ratio * fmaf(cos_t, n.z, u.z)};
-      const float par = -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+      const float par = -rt_sqrt(fabsf(1.0f - dot3(perp, perp)));
       nd.x = fmaf(par, n.x, perp.x); nd.y = fmaf(par, n.y, perp.y); nd.z = fmaf(par, n.z, perp.z);
     }
   } else {
     float l2;
     const f3 b = unit_ball(g, l2);
     if (s.kind == kLambertian) {  // hitrecord.nim:82-92
-      const float ib = 1.0f / sqrtf(l2);
+      const float ib = rt_rcp(rt_sqrt(l2));
       nd.x = fmaf(b.x, ib, n.x); nd.y = fmaf(b.y, ib, n.y); nd.z = fmaf(b.z, ib, n.z);
       if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;  // nearZero
     } else {                      // Metal, hitrecord.nim:94-99

@@ -517,3 +517,11 @@ def test_progressive_passes_reach_the_single_render_image(gpu_renderer):
         gpu_renderer.renderPass(W, H, 500, 1, 50, seed=1, rows=[60, 3, 4, 5])  # other seed
     gpu_renderer.renderPass(W, H, 500, 12, 50, rows=[60, 3, 4, 5])              # a proper continuation still works
     assert (gpu_renderer.readImage()[0] == gpu_renderer.renderRows(W, H, 512, 50, rows=[60, 3, 4, 5])[0]).all()
+
+
+def test_device_sqrt_and_reciprocal_are_correctly_rounded(gpu_renderer):
+    """The kernels' own sqrt / reciprocal sequences against the compiler's IEEE ones, all 2^32 inputs."""
+    from raytracinginoneweekend_amd import _lib
+    bad = (_lib.C.c_uint64 * 2)()
+    _lib.check(gpu_renderer._lib.rtow_selftest_arithmetic(gpu_renderer._h, bad))
+    assert list(bad) == [0, 0]
