@@ -14,6 +14,7 @@
 // streams the sphere table through SGPRs with wave-uniform scalar loads, four spheres per load,
 // two spheres per packed FP32 instruction, and a rarely taken branch for discriminant >= 0.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "rtow_kernels.h"
 
 namespace rtow {
@@ -339,6 +340,16 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
         e_end = left < want ? (uint32_t)left : want;
        }
         // ---- generate: the next (up to) 64 paths of the chunk, one per lane, ALL lanes at work
+        // The camera (19 scalars) is read from the kernel arguments here, every time: kept in scalar
+        // registers across the sphere scan it pushes other values out into vector-register lanes.
+        typedef const float __attribute__((address_space(4)))* karg_ptr;
+        karg_ptr cf = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();   // TraceParams starts with cam: 19 floats
+        asm volatile("" : "+s"(cf));
+        static_assert(offsetof(TraceParams, cam) == 0 && sizeof(CameraParams) == 19 * sizeof(float), "camera layout");
+        CameraParams cam;
+        cam.origin = {cf[0], cf[1], cf[2]}; cam.llc = {cf[3], cf[4], cf[5]}; cam.hor = {cf[6], cf[7], cf[8]};
+        cam.ver = {cf[9], cf[10], cf[11]}; cam.u = {cf[12], cf[13], cf[14]}; cam.v = {cf[15], cf[16], cf[17]};
+        cam.lens_radius = cf[18];
         const uint32_t n_gen = min(64u, e_end - e_next);
         const bool gen = lane < n_gen;
         // (pixel, sample) of lane's path: e counts samples from the first sample of the chunk's
@@ -360,7 +371,7 @@ __global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const Trac
           const int y = P.rows ? P.rows[r] : (int)r;
           Stream g2 = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + P.sample_base);
           f3 o2, d2;
-          camera_ray(P.cam, ci, P.H - 1 - y, P.W, P.H, g2, o2, d2);
+          camera_ray(cam, ci, P.H - 1 - y, P.W, P.H, g2, o2, d2);
           pool[0 * 64 + lane] = __float_as_uint(o2.x); pool[1 * 64 + lane] = __float_as_uint(o2.y);
           pool[2 * 64 + lane] = __float_as_uint(o2.z); pool[3 * 64 + lane] = __float_as_uint(d2.x);
           pool[4 * 64 + lane] = __float_as_uint(d2.y); pool[5 * 64 + lane] = __float_as_uint(d2.z);
