@@ -227,7 +227,7 @@ static __device__ __forceinline__ void wave_flush(unsigned long long* accum, boo
 }
 
 template <bool K_LDS>
-__global__ void __launch_bounds__(kTraceThreads, 6) rtow_trace_kernel(const TraceParams P) {
+__global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
   // LDS: candidate stacks [4 waves][kCandDepth][64], path pools [4 waves][kPoolFields][64], then
   // (K_LDS) -k per sphere
   extern __shared__ f4v lds_raw[];
