@@ -14,8 +14,8 @@ so total work is fixed ("strong" scaling).
 
 Prints ONE JSON line on rank 0.  value = ray segments (world.hit queries) of all ranks / wall
 seconds / 1e6.  roofline: algorithmic FLOP (18 per ray-sphere test, 18*N+65 per segment) over
-the trace kernel's own duration, measured with HIP events on the stream it runs on in two
-un-overlapped steps after the timed region.
+the trace kernel's own duration, measured with HIP events on the stream it runs on in three
+un-overlapped steps after the timed region (the median of the three).
 cpu_baseline: the FP64 CPU restatement of the reference (oracle/, "port") timed on this box's
 host cores on a bounded sample of the same frame.
 """
@@ -186,14 +186,15 @@ def main():
 
     # one frame at a time, for the kernel's own duration (launches that overlap stretch each other)
     # and for the latency of a single step
-    serial = []
-    t1 = time.perf_counter()
-    for i in range(2):
+    serial, serial_wall = [], []
+    for i in range(3):
+        t1 = time.perf_counter()
         enqueue(i)
         serial.append(finish(i))
-    serial_ms = (time.perf_counter() - t1) / 2 * 1e3
-    trace_ms = [st["trace_ms"] for st in serial]
-    total_ms = [st["total_ms"] for st in serial]
+        serial_wall.append((time.perf_counter() - t1) * 1e3)
+    serial_ms = sorted(serial_wall)[1]                      # medians of three: one slow launch (clock
+    trace_ms = [sorted(st["trace_ms"] for st in serial)[1]]  # transients between phases) does not decide
+    total_ms = [sorted(st["total_ms"] for st in serial)[1]]
 
     if world > 1:
         red_dev = f"cuda:{device}" if args.backend == "nccl" else "cpu"

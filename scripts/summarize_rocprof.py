@@ -17,7 +17,7 @@ if os.path.exists(trace):
         lines.append(",".join(str(x) for x in r))
     lines.append("")
     lines.append("# dispatches of the trace kernel, in start order.  bench.py keeps two steps in flight, so launches of")
-    lines.append("# the timed region overlap their neighbours (overlap_ns > 0) and stretch each other; the last two launches")
+    lines.append("# the timed region overlap their neighbours (overlap_ns > 0) and stretch each other; the last three launches")
     lines.append("# run one at a time and are the ones roofline.kernel_ms is taken from")
     lines.append("name,start_ns,duration_ns,overlap_with_previous_ns,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size")
     rows = list(c.execute("select name,start,end,duration,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size "
