@@ -187,7 +187,7 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     s.kind = kind[j]; s.ir = ir[j]; s.inv_ir = 1.0f / ir[j]; s.pad_ = 0.f;
     if (kind[j] == RTOW_DIELECTRIC) {
       // a dielectric has no albedo (hitrecord.nim:109): its slots carry Schlick's r0^2 (hitrecord.nim:103-104)
-      // for the two refraction ratios a hit can see, evaluated here exactly as the kernel used to
+      // for the two refraction ratios a hit can see, in the binary32 operations the CPU mirror uses per hit
       s.ar = rtow::schlick_r0(s.inv_ir);   // front face: ratio = 1 / ir
       s.ag = rtow::schlick_r0(s.ir);       // back face:  ratio = ir
       s.ab = 0.f;
@@ -212,6 +212,8 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
     if (v >= 1 && v < c->blocks_per_cu) c->blocks_per_cu = v;
   }
   c->have_scene = true;
+  c->samples_done = 0;              // accumulated samples belong to the previous scene: no pass may continue them
+  c->last_row_list_valid = false;
   return RTOW_OK;
 }
 
@@ -222,6 +224,8 @@ int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
   c->cam.ver = v3(cam->vertical); c->cam.u = v3(cam->u); c->cam.v = v3(cam->v);
   c->cam.lens_radius = cam->lens_radius;
   c->have_camera = true;
+  c->samples_done = 0;              // likewise for the previous camera
+  c->last_row_list_valid = false;
   return RTOW_OK;
 }
 

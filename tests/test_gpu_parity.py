@@ -516,6 +516,10 @@ def test_progressive_passes_reach_the_single_render_image(gpu_renderer):
     with pytest.raises(_lib.RtowError):
         gpu_renderer.renderPass(W, H, 500, 1, 50, seed=1, rows=[60, 3, 4, 5])  # other seed
     gpu_renderer.renderPass(W, H, 500, 12, 50, rows=[60, 3, 4, 5])              # a proper continuation still works
+    gpu_renderer.sync()
+    gpu_renderer.setCamera(R.bookCamera(W / H))                                 # a new camera (or scene) ends the image
+    with pytest.raises(_lib.RtowError):
+        gpu_renderer.renderPass(W, H, 512, 1, 50, rows=[60, 3, 4, 5])
     assert (gpu_renderer.readImage()[0] == gpu_renderer.renderRows(W, H, 512, 50, rows=[60, 3, 4, 5])[0]).all()
 
 
