@@ -49,6 +49,7 @@ struct Ray { float ox, oy, oz, ux, uy, uz; };
 
 // One wave = 64 rays.  table: per batch of 16 spheres, per MFMA m (0, 1), per lane: 8 bf16 (uint4).
 // out (optional): value per (ray, sphere) for the first `n_out_rays` rays.  survivors: total count.
+template <bool WRITE_OUT>
 __global__ void __launch_bounds__(256) screen_kernel(const Ray* rays, const uint4* table, int n_batches, float cmax2,
                                                      float margin_scale, float* out, int n_out_rays, int n_spheres,
                                                      unsigned long long* survivors, int iters, unsigned long long* clk) {
@@ -101,12 +102,12 @@ __global__ void __launch_bounds__(256) screen_kernel(const Ray* rays, const uint
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 acc = accs[g];
-        const float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-        if (mx >= thr[g]) {
+        // four compares and scalar ORs: fmaxf on matrix results would first canonicalise every operand
+        if ((acc[0] >= thr[g]) | (acc[1] >= thr[g]) | (acc[2] >= thr[g]) | (acc[3] >= thr[g])) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) count += acc[q] >= thr[g] ? 1u : 0u;
         }
-        if (out && it == 0) {
+        if (WRITE_OUT && it == 0) {
           const int ray = (blockIdx.x * 4 + wave) * 64 + 16 * g + (lane & 15);
           if (ray < n_out_rays)
 #pragma unroll
@@ -185,7 +186,7 @@ int main() {
   CK(hipMemcpy(d_table, table.data(), table.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemset(d_surv, 0, 8));
   const float cmax2 = (float)(cmax * cmax);
-  screen_kernel<<<n_blocks, 256>>>(d_rays, d_table, n_batches, cmax2, 1.0f, d_out, n_out, n, d_surv, 1, d_clk);
+  screen_kernel<true><<<n_blocks, 256>>>(d_rays, d_table, n_batches, cmax2, 1.0f, d_out, n_out, n, d_surv, 1, d_clk);
   CK(hipDeviceSynchronize());
   std::vector<float> out((size_t)n_out * n);
   CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
@@ -218,9 +219,9 @@ int main() {
   for (int blocks_per_cu : {2, 3, 4}) {
     const int grid = 256 * blocks_per_cu, iters = 200;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    screen_kernel<<<grid, 256>>>(d_rays, d_table, n_batches, cmax2, 1.0f, nullptr, 0, n, d_surv, 20, d_clk);
+    screen_kernel<false><<<grid, 256>>>(d_rays, d_table, n_batches, cmax2, 1.0f, nullptr, 0, n, d_surv, 20, d_clk);
     CK(hipEventRecord(e0));
-    screen_kernel<<<grid, 256>>>(d_rays, d_table, n_batches, cmax2, 1.0f, nullptr, 0, n, d_surv, iters, d_clk);
+    screen_kernel<false><<<grid, 256>>>(d_rays, d_table, n_batches, cmax2, 1.0f, nullptr, 0, n, d_surv, iters, d_clk);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long clk; CK(hipMemcpy(&clk, d_clk, 8, hipMemcpyDeviceToHost));
