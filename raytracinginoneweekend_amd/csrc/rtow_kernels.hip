@@ -124,13 +124,14 @@ static __device__ __forceinline__ void cand_push(CandStack& c, bool pass, int j)
   c.n += pass ? 1u : 0u;
 }
 
-static __device__ __forceinline__ void cand_drain(CandStack& c, const float4* __restrict__ exact, f3 o, f3 u,
+template <typename ExactPtr>
+static __device__ __forceinline__ void cand_drain(CandStack& c, ExactPtr exact, f3 o, f3 u,
                                                   float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
   for (uint32_t i = 0; __ballot(i < c.n) != 0; ++i) {
     RTOW_COUNT(10, 1);
     if (i < c.n) {
       const int j = (int)c.slot[i * 64u];
-      const float4 sp = exact[j];   // (cx, cy, cz, r^2)
+      const f4v sp = exact[j];   // (cx, cy, cz, r^2)
       const float ocx = o.x - sp.x, ocy = o.y - sp.y, ocz = o.z - sp.z;
       float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
       float m = fmaf(-ocx, ocx, sp.w); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
@@ -143,7 +144,8 @@ static __device__ __forceinline__ void cand_drain(CandStack& c, const float4* __
   c.n = 0;
 }
 
-static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, int j, const float4* exact,
+template <typename ExactPtr>
+static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, int j, ExactPtr exact,
                                                   CandStack& cand, const ScanRay& r, f3 o, f3 u, float tmin, int prev,
                                                   float& best, int& id RTOW_PROF_PARAM) {
   const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, nk.xy, r);
@@ -170,8 +172,8 @@ static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, 
 // the SGPR copy of k (moved to VGPRs first; same arithmetic, two more instructions per group).
 typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 
-template <bool K_LDS>
-static __device__ __forceinline__ void scan_regular(geom_ptr geom, const float4* exact, const f4v* nk_lds,
+template <bool K_LDS, typename ExactPtr>
+static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exact, const f4v* nk_lds,
                                                     CandStack& cand, int n_groups, float cmax, f3 o, f3 u, float tmin,
                                                     int prev, float& best, int& id RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
@@ -226,10 +228,13 @@ static __device__ __forceinline__ void wave_flush(unsigned long long* accum, boo
   }
 }
 
-template <bool K_LDS>
+// K_LDS: -k per sphere in LDS (tables up to kMaxSpheresKInLds entries).  X_LDS: the records of the
+// exact test (16 bytes per sphere) in LDS as well (tables up to kMaxSpheresExactInLds entries): a
+// round of exact tests then waits for LDS, not for L2.
+template <bool K_LDS, bool X_LDS>
 __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
   // LDS: candidate stacks [4 waves][kCandDepth][64], path pools [4 waves][kPoolFields][64], then
-  // (K_LDS) -k per sphere
+  // (K_LDS) -k per sphere, then (X_LDS) the exact-test records
   extern __shared__ f4v lds_raw[];
   uint32_t* const stacks = (uint32_t*)lds_raw;
   uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandDepth * 64 + (threadIdx.x >> 6) * (kPoolFields * 64);
@@ -243,8 +248,14 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     const int n4 = P.n_geom_pad / 4 + 1;
     f4v* const dst = lds_raw + (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64 / 4;
     for (int i = threadIdx.x; i < n4; i += kTraceThreads) dst[i] = ((const f4v*)P.geom_nk)[i];
+    if (X_LDS) {
+      f4v* const xdst = dst + n4;
+      for (int i = threadIdx.x; i < P.n_geom_pad; i += kTraceThreads) xdst[i] = ((const f4v*)P.geom_exact)[i];
+    }
     __syncthreads();
   }
+  typedef const f4v __attribute__((address_space(3)))* exact_lds_ptr;
+  const exact_lds_ptr exact_lds = (exact_lds_ptr)(nk_lds + (P.n_geom_pad / 4 + 1));
 
   // wave-uniform: the chunk being handed out.  A chunk is a run of consecutive paths in
   // pixel-major order (all samples of a pixel, then the next pixel of the row list).
@@ -432,7 +443,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       }
     }
     const unsigned long long t_scan0 = RTOW_CLOCK();
-    if (alive) scan_regular<K_LDS>(geom, P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    if (alive) {
+      if (X_LDS) scan_regular<K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+      else scan_regular<K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    }
     const unsigned long long t_scan1 = RTOW_CLOCK();
 #ifdef RTOW_PROFILE_COUNTERS
     uint32_t shade_draws = 0;
@@ -513,13 +527,17 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
 
 static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64; }
 static size_t k_lds_bytes(int n_geom_pad) { return stack_lds_bytes() + sizeof(float) * (size_t)(n_geom_pad + 4); }
+static size_t kx_lds_bytes(int n_geom_pad) { return k_lds_bytes(n_geom_pad) + sizeof(float4) * (size_t)n_geom_pad; }
 
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream) {
-  if (p.n_geom_pad <= kMaxSpheresKInLds)
-    hipLaunchKernelGGL(rtow_trace_kernel<true>, dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
+  if (p.n_geom_pad <= kMaxSpheresExactInLds)
+    hipLaunchKernelGGL((rtow_trace_kernel<true, true>), dim3(grid_blocks), dim3(kTraceThreads), kx_lds_bytes(p.n_geom_pad),
+                       stream, p);
+  else if (p.n_geom_pad <= kMaxSpheresKInLds)
+    hipLaunchKernelGGL((rtow_trace_kernel<true, false>), dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
                        stream, p);
   else
-    hipLaunchKernelGGL(rtow_trace_kernel<false>, dim3(grid_blocks), dim3(kTraceThreads), stack_lds_bytes(), stream, p);
+    hipLaunchKernelGGL((rtow_trace_kernel<false, false>), dim3(grid_blocks), dim3(kTraceThreads), stack_lds_bytes(), stream, p);
 }
 
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
@@ -676,10 +694,12 @@ extern "C" int rtow_debug_wave_times(unsigned long long* out, int n_waves) {
 int trace_blocks_per_cu(int n_geom_pad) {
   int nb = 0;
   hipError_t e;
-  if (n_geom_pad <= kMaxSpheresKInLds)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true>, kTraceThreads, k_lds_bytes(n_geom_pad));
+  if (n_geom_pad <= kMaxSpheresExactInLds)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, true>, kTraceThreads, kx_lds_bytes(n_geom_pad));
+  else if (n_geom_pad <= kMaxSpheresKInLds)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, false>, kTraceThreads, k_lds_bytes(n_geom_pad));
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false>, kTraceThreads, stack_lds_bytes());
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false, false>, kTraceThreads, stack_lds_bytes());
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
