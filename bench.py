@@ -196,6 +196,13 @@ def main():
     trace_ms = [sorted(st["trace_ms"] for st in serial)[1]]  # transients between phases) does not decide
     total_ms = [sorted(st["total_ms"] for st in serial)[1]]
 
+    # the frame assembled from all ranks' tiles against the same frame rendered whole on rank 0
+    image_verified = None
+    if world > 1 and rank == 0:
+        last = gatherers[2 % depth_in_flight].full          # gathered by the last serial step
+        whole = renderers[0].renderRows(width, height, spp, depth, seed)[0]
+        image_verified = bool((last.cpu().numpy() == whole).all())
+
     if world > 1:
         red_dev = f"cuda:{device}" if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -231,6 +238,7 @@ def main():
                     f"interleaved {tile}-row tiles over {world} GPUs + RCCL all_gather of 8-bit rows" if args.backend == "nccl"
                     else f"REHEARSAL: {world} gloo ranks sharing devices (not a benchmark)"),
                 "frames_in_flight": depth_in_flight,
+                "gathered_image_equals_single_gpu_render": image_verified,
                 "latency_ms_per_step": serial_ms,
                 "paths_per_step": paths,
                 "segments_per_step": segments // max(1, args.steps),
