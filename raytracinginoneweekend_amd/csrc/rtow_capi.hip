@@ -72,6 +72,8 @@ struct rtow_ctx {
   bool image_in_workspace = false;            // the last render left its 8-bit image in `rgb`
   DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
   uint64_t* host_counters = nullptr;          // pinned, 16 bytes
+  char* staging[2] = {nullptr, nullptr};      // pinned, kStagingBytes each: large device-to-host copies go through them
+  hipEvent_t staging_ev[2] = {nullptr, nullptr};
 
   // last render
   bool pending = false;
@@ -82,6 +84,35 @@ struct rtow_ctx {
   bool last_row_list_valid = false;
   rtow_stats stats = {};
 };
+
+// Device-to-host copy of a large buffer into ordinary (pageable) caller memory: the runtime stages
+// such copies through a small internal buffer at a few GB/s; two pinned 8 MB buffers used in turn -
+// one being filled by the copy engine while the host empties the other - run at PCIe rate.
+constexpr size_t kStagingBytes = 8u << 20;
+static int copy_to_host(rtow_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+  if (bytes < 2 * kStagingBytes) {
+    HIP_TRY(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
+    return RTOW_OK;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (!c->staging[k]) HIP_TRY(hipHostMalloc((void**)&c->staging[k], kStagingBytes, hipHostMallocDefault));
+    if (!c->staging_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->staging_ev[k], hipEventDisableTiming));
+  }
+  const size_t n_chunks = (bytes + kStagingBytes - 1) / kStagingBytes;
+  auto chunk_bytes = [&](size_t i) { return i + 1 < n_chunks ? kStagingBytes : bytes - i * kStagingBytes; };
+  auto issue = [&](size_t i) -> hipError_t {
+    hipError_t e = hipMemcpyAsync(c->staging[i & 1], (const char*)src_dev + i * kStagingBytes, chunk_bytes(i),
+                                  hipMemcpyDeviceToHost, c->stream);
+    return e == hipSuccess ? hipEventRecord(c->staging_ev[i & 1], c->stream) : e;
+  };
+  HIP_TRY(issue(0));
+  for (size_t i = 0; i < n_chunks; ++i) {
+    if (i + 1 < n_chunks) HIP_TRY(issue(i + 1));
+    HIP_TRY(hipEventSynchronize(c->staging_ev[i & 1]));
+    memcpy((char*)dst + i * kStagingBytes, c->staging[i & 1], chunk_bytes(i));
+  }
+  return RTOW_OK;
+}
 
 extern "C" {
 
@@ -128,6 +159,10 @@ int rtow_destroy(rtow_ctx* c) {
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release();
   if (c->host_counters) (void)hipHostFree(c->host_counters);
+  for (int k = 0; k < 2; ++k) {
+    if (c->staging[k]) (void)hipHostFree(c->staging[k]);
+    if (c->staging_ev[k]) (void)hipEventDestroy(c->staging_ev[k]);
+  }
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -461,7 +496,7 @@ int rtow_format_ppm(rtow_ctx* c, int binary, char* out, uint64_t capacity, uint6
     return fail(RTOW_ERR_INVALID, "rtow_format_ppm: %llu bytes needed, capacity %llu", (unsigned long long)total_len,
                 (unsigned long long)capacity);
   memcpy(out, header, (size_t)header_len);
-  if (body) HIP_TRY(hipMemcpy(out + header_len, binary ? c->rgb.p : c->ppm_text.p, (size_t)body, hipMemcpyDeviceToHost));
+  if (body) return copy_to_host(c, out + header_len, binary ? c->rgb.p : c->ppm_text.p, (size_t)body);
   return RTOW_OK;
 }
 

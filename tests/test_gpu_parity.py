@@ -365,6 +365,13 @@ def test_device_side_ppm_text_matches_host_writer(gpu_renderer):
         if W == 1200:   # one-, two- and three-digit values all occur in a full frame
             vals = set(text.split()[4:])
             assert {b"0", b"255"} <= vals and any(len(v) == 2 for v in vals)
+    # a frame whose P6 body (24.9 MB) takes the staged copy path
+    gpu_renderer.setCamera(R.bookCamera(3840 / 2160))
+    big = gpu_renderer.renderRows(3840, 2160, 1, 4)[0]
+    p6 = gpu_renderer.ppm(binary=True)
+    assert p6[:17] == b"P6\n3840 2160\n255\n" and p6[17:] == big.tobytes()
+    gpu_renderer.renderRows(64, 48, 1, 50, rows=[5, 0, 47])
+    text = gpu_renderer.ppm()
     n = _lib.C.c_uint64(0)
     with pytest.raises(_lib.RtowError) as e:   # buffer too small: error, needed length still reported
         _lib.check(gpu_renderer._lib.rtow_format_ppm(gpu_renderer._h, 0, np.empty(8, np.uint8).ctypes.data, 8, _lib.C.byref(n)))
