@@ -125,6 +125,100 @@ __global__ void __launch_bounds__(256) screen_kernel(const Ray* rays, const uint
   if (lane == 0) atomicAdd(survivors, (unsigned long long)count);
 }
 
+// Second probe: the screen as the renderer would run it.  One 1024-thread workgroup per CU (four
+// waves per SIMD); the operand table sits in LDS; every "segment" rebuilds the ray fragments (staged
+// 16 rays at a time through 2 KB of LDS per wave) and hands every survivor from the lane that holds
+// the result to the stack of the lane that owns the ray (LDS atomic on the owner's counter).
+constexpr int kScanWaves = 16, kDepth = 12;
+__global__ void __launch_bounds__(1024) scan_kernel(const Ray* rays, const uint4* table, int n_batches, float cmax2,
+                                                    unsigned long long* survivors, int iters, unsigned long long* clk) {
+  extern __shared__ uint4 lds[];
+  uint4* const tab = lds;                                             // n_batches * 2 * 64
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint4* const stage = tab + (size_t)n_batches * 128 + wave * 128;    // 16 rays x 8 uint4 (2 KB)
+  uint32_t* const wave_words = (uint32_t*)(tab + (size_t)n_batches * 128 + kScanWaves * 128) + wave * (kDepth + 1) * 64;
+  uint32_t* const cnt = wave_words;                                   // 64 counters
+  uint32_t* const stack = wave_words + 64;                            // [kDepth][64]
+  for (int i = threadIdx.x; i < n_batches * 128; i += 1024) tab[i] = table[i];
+  __syncthreads();
+  const Ray r = rays[(blockIdx.x * kScanWaves + wave) * 64 + lane];
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned int total = 0;
+  for (int it = 0; it < iters; ++it) {
+    // ---- per segment: ray terms, fragments, thresholds
+    const float ox = r.ox + 1e-6f * (float)it;   // keeps the compiler from hoisting the segment set-up
+    const float ou = ox * r.ux + r.oy * r.uy + r.oz * r.uz;
+    const float wx = 2.0f * (ox - ou * r.ux), wy = 2.0f * (r.oy - ou * r.uy), wz = 2.0f * (r.oz - ou * r.uz);
+    const float term[10] = {r.ux * r.ux, r.uy * r.uy, r.uz * r.uz, r.ux * r.uy, r.ux * r.uz, r.uy * r.uz, wx, wy, wz, 1.0f};
+    const float oo = ox * ox + r.oy * r.oy + r.oz * r.oz;
+    const float threshold = (oo - ou * ou) - (1.0f / 262144.0f) * (oo + cmax2);
+    uint32_t slot_words[32];   // 64 bf16 slots, two to a word
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      uint32_t p[3];
+      d_split3(term[t], p);
+      // slots 6t .. 6t+5 hold ray pieces {1,2,1,3,2,1}: words 3t .. 3t+2
+      slot_words[3 * t] = p[0] | (p[1] << 16);
+      slot_words[3 * t + 1] = p[0] | (p[2] << 16);
+      slot_words[3 * t + 2] = p[1] | (p[0] << 16);
+    }
+    slot_words[30] = 0; slot_words[31] = 0;
+    bf16x8 B[4][2];
+    float thr[4];
+    cnt[lane] = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if ((lane >> 4) == g) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+          stage[(lane & 15) * 8 + w] = make_uint4(slot_words[4 * w], slot_words[4 * w + 1], slot_words[4 * w + 2], slot_words[4 * w + 3]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const uint4 v = stage[(lane & 15) * 8 + 4 * m + (lane >> 4)];   // slots 32 m + 8 (lane >> 4) .. + 7
+        memcpy(&B[g][m], &v, 16);
+      }
+      thr[g] = __shfl(threshold, 16 * g + (lane & 15), 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    // ---- scan
+    uint4 n0 = tab[lane], n1 = tab[64 + lane];
+    for (int b = 0; b < n_batches; ++b) {
+      const uint4 a0 = n0, a1 = n1;
+      const int nb = b + 1 < n_batches ? b + 1 : 0;
+      n0 = tab[(size_t)(2 * nb) * 64 + lane]; n1 = tab[(size_t)(2 * nb + 1) * 64 + lane];
+      bf16x8 A0, A1;
+      memcpy(&A0, &a0, 16); memcpy(&A1, &a1, 16);
+      f32x4 accs[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { const f32x4 z = {0, 0, 0, 0}; accs[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B[g][0], z, 0, 0, 0); }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accs[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B[g][1], accs[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (accs[g][q] >= thr[g]) {   // rare per (g, q): the owner's stack takes the list index
+            const uint32_t owner = 16u * g + (lane & 15u);
+            const uint32_t pos = atomicAdd(&cnt[owner], 1u);
+            if (pos < (uint32_t)kDepth) stack[pos * 64u + owner] = 16u * b + 4u * (lane >> 4) + q;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t mine = cnt[lane];
+    total += mine;
+    if (mine) total += stack[lane] & 0u;   // the stack is read by its owner
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == 3 && threadIdx.x == 0) clk[0] = t1 - t0;
+  for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+  if (lane == 0) atomicAdd(survivors, (unsigned long long)total);
+}
+
 int main() {
   // a scene shaped like the reference's: 22 x 22 grid of r = 0.2 spheres plus three of r = 1
   std::vector<double> cx, cy, cz, rr;
@@ -229,6 +323,25 @@ int main() {
     const double simd_cycles_per_sphere_wave = (double)clk / ((double)iters * n_batches * 16) / blocks_per_cu;
     printf("waves/SIMD %d: %.3f ms, one wave %.1f cycles per sphere (wall), %.2f SIMD cycles per sphere and wave "
            "(VALU screen today: 16.4)\n", blocks_per_cu, ms, (double)clk / ((double)iters * n_batches * 16), simd_cycles_per_sphere_wave);
+  }
+  {
+    const size_t lds_bytes = (size_t)n_batches * 128 * 16 + kScanWaves * 128 * 16 + (size_t)kScanWaves * (kDepth + 1) * 64 * 4;
+    CK(hipFuncSetAttribute((const void*)scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const int grid = 256, iters = 50;   // one workgroup of 16 waves per CU; rays 0 .. 256*1024-1
+    CK(hipMemset(d_surv, 0, 8));
+    scan_kernel<<<grid, 1024, lds_bytes>>>(d_rays, d_table, n_batches, cmax2, d_surv, 1, d_clk);
+    CK(hipDeviceSynchronize());
+    unsigned long long s1 = 0; CK(hipMemcpy(&s1, d_surv, 8, hipMemcpyDeviceToHost));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    scan_kernel<<<grid, 1024, lds_bytes>>>(d_rays, d_table, n_batches, cmax2, d_surv, iters, d_clk);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long clk; CK(hipMemcpy(&clk, d_clk, 8, hipMemcpyDeviceToHost));
+    printf("renderer-shaped scan (LDS operands %zu KB of LDS per CU, fragments rebuilt per segment, survivors handed to their owners):\n"
+           "  %.3f ms, survivors per ray %.3f (first probe: %.3f), one wave %.1f cycles per sphere (wall), %.2f SIMD cycles per sphere "
+           "and wave at 4 waves/SIMD (VALU screen today: 16.4)\n", lds_bytes / 1024, ms, (double)s1 / (grid * 1024.0), (double)surv / n_rays,
+           (double)clk / ((double)iters * n_batches * 16), (double)clk / ((double)iters * n_batches * 16) / 4.0);
   }
   return 0;
 }
