@@ -449,10 +449,11 @@ def test_random_scenes_bit_exact(oracle):
     from raytracinginoneweekend_amd.basetypes import point, vec3
     from raytracinginoneweekend_amd.camera import initCamera
     R = _R()
-    rng = np.random.default_rng(20241111)
+    # RTOW_FUZZ_SEED / RTOW_FUZZ_CASES: other worlds and more of them for soak runs
+    rng = np.random.default_rng(int(os.environ.get("RTOW_FUZZ_SEED", "20241111")))
     W, H = 48, 32
     with R.Renderer(0) as r:
-        for case in range(24):
+        for case in range(int(os.environ.get("RTOW_FUZZ_CASES", "24"))):
             n = int(rng.integers(1, 61))
             spread = float(rng.choice([1.0, 4.0, 15.0]))
             center = rng.normal(0.0, spread, (n, 3))
