@@ -300,9 +300,15 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   HIP_TRY(c->accum.reserve(sizeof(unsigned long long) * 3 * (n_pixels ? n_pixels : 1)));
   HIP_TRY(c->rgb.reserve(3 * (n_pixels ? n_pixels : 1)));
   if (want_hit_id) HIP_TRY(c->hit_id.reserve(sizeof(int32_t) * (n_pixels ? n_pixels : 1)));
+  if (first_sample == 0) {
+    if (rows) c->last_row_list.assign(rows, rows + n_rows); else c->last_row_list.clear();
+    c->last_row_list_valid = true;
+  }
   if (rows) {
+    // uploaded from the context's own copy: the caller may release rows[] as soon as this call returns
     HIP_TRY(c->rows.reserve(sizeof(int32_t) * (size_t)(n_rows ? n_rows : 1)));
-    HIP_TRY(hipMemcpyAsync(c->rows.p, rows, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->rows.p, c->last_row_list.data(), sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice,
+                           c->stream));
   }
 
   rtow::TraceParams p;
@@ -346,10 +352,6 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   c->last_w = w; c->last_h = h; c->last_spp = spp; c->last_rows = n_rows;
   c->samples_done = first_sample + spp;
   c->last_seed = seed;
-  if (first_sample == 0) {
-    if (rows) c->last_row_list.assign(rows, rows + n_rows); else c->last_row_list.clear();
-    c->last_row_list_valid = true;
-  }
   return RTOW_OK;
 }
 
@@ -387,9 +389,8 @@ int rtow_read_image(rtow_ctx* c, uint8_t* rgb_out, uint64_t* accum_out) {
   const int rc = rtow_sync(c);
   if (rc != RTOW_OK) return rc;
   const size_t n_pixels = (size_t)c->last_rows * (size_t)c->last_w;
-  if (rgb_out && n_pixels) HIP_TRY(hipMemcpy(rgb_out, c->rgb.p, 3 * n_pixels, hipMemcpyDeviceToHost));
-  if (accum_out && n_pixels)
-    HIP_TRY(hipMemcpy(accum_out, c->accum.p, sizeof(uint64_t) * 3 * n_pixels, hipMemcpyDeviceToHost));
+  if (rgb_out && n_pixels) { const int r2 = copy_to_host(c, rgb_out, c->rgb.p, 3 * n_pixels); if (r2 != RTOW_OK) return r2; }
+  if (accum_out && n_pixels) return copy_to_host(c, accum_out, c->accum.p, sizeof(uint64_t) * 3 * n_pixels);
   return RTOW_OK;
 }
 
@@ -400,11 +401,12 @@ int rtow_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed
   rc = rtow_sync(c);
   if (rc != RTOW_OK) return rc;
   const size_t n_pixels = (size_t)n_rows * (size_t)w;
-  if (rgb_out && n_pixels) HIP_TRY(hipMemcpy(rgb_out, c->rgb.p, 3 * n_pixels, hipMemcpyDeviceToHost));
-  if (accum_out && n_pixels)
-    HIP_TRY(hipMemcpy(accum_out, c->accum.p, sizeof(uint64_t) * 3 * n_pixels, hipMemcpyDeviceToHost));
-  if (hit_id_out && n_pixels)
-    HIP_TRY(hipMemcpy(hit_id_out, c->hit_id.p, sizeof(int32_t) * n_pixels, hipMemcpyDeviceToHost));
+  if (rgb_out && n_pixels) { rc = copy_to_host(c, rgb_out, c->rgb.p, 3 * n_pixels); if (rc != RTOW_OK) return rc; }
+  if (accum_out && n_pixels) {
+    rc = copy_to_host(c, accum_out, c->accum.p, sizeof(uint64_t) * 3 * n_pixels);
+    if (rc != RTOW_OK) return rc;
+  }
+  if (hit_id_out && n_pixels) return copy_to_host(c, hit_id_out, c->hit_id.p, sizeof(int32_t) * n_pixels);
   return RTOW_OK;
 }
 
