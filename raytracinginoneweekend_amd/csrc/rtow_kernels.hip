@@ -120,8 +120,12 @@ struct CandStack {
 };
 
 static __device__ __forceinline__ void cand_push(CandStack& c, bool pass, int j) {
-  if (pass) c.slot[c.n * 64u] = (uint32_t)j;
-  c.n += pass ? 1u : 0u;
+  // Usually one of a group's four spheres has survivors; a wave-uniform branch skips the other three
+  // pushes (instructions issued with an empty execution mask still take their issue slots).
+  if (__ballot(pass) != 0) {
+    if (pass) c.slot[c.n * 64u] = (uint32_t)j;
+    c.n += pass ? 1u : 0u;
+  }
 }
 
 template <typename ExactPtr>
