@@ -4,10 +4,10 @@
 //                      iterative bounce loop and is refilled with a new path the moment its
 //                      path ends, so the sphere scan always runs with full wavefronts.  Work is
 //                      handed out in chunks (runs of consecutive paths, pixel-major) from a global
-//                      counter, in sizes that shrink as the frame runs out.  Radiance is summed per lane in 64-bit fixed point; when lanes move
-//                      on to another pixel their sums are combined with a wavefront reduction
-//                      and added to the frame with integer atomics, which makes the image
-//                      independent of scheduling, chunking and GPU count.
+//                      counter, in sizes that shrink as the frame runs out.  Radiance is summed per lane in
+//                      64-bit fixed point; a lane that moves on to another pixel adds its sums to
+//                      the frame with integer atomics, which makes the image independent of
+//                      scheduling, chunking and GPU count.
 //  rtow_resolve_kernel mean + sqrt gamma + clamp + 8-bit quantisation (raytracer.nim:22-28).
 //
 // The sphere scan (hittables.nim:79-88 over hitrecord.nim:55-63) keeps the ray in VGPRs and
@@ -208,27 +208,19 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
   return v;
 }
 
-// Per-pixel accumulation across the wavefront.  Lanes with `want` set hold finished partial
-// sums (fixed point) for pixel `accpix`.  Lanes of the same pixel are added up with a wavefront
-// reduction and ONE lane issues the three 64-bit atomics, so a pixel costs a handful of atomics
-// per wave instead of three per lane.  Must be called by all 64 lanes together.
-static __device__ __forceinline__ void wave_flush(unsigned long long* accum, bool want, uint32_t accpix,
+// A lane keeps the fixed-point radiance sums of the pixel it is working on in registers (about eight
+// paths in a row belong to the same pixel at spp 500) and hands them to the image when it moves on to
+// another pixel: three 64-bit atomics, result unused.  Integer sums do not depend on the order they
+// arrive in.  (Adding up the lanes of one pixel across the wavefront first - one set of atomics per
+// pixel and wave - cuts the memory traffic tenfold but costs more VALU instructions than it saves:
+// the lanes of a wave change pixel a few at a time, and every such round paid for a full reduction.)
+static __device__ __forceinline__ void flush_sums(unsigned long long* accum, bool want, uint32_t accpix,
                                                   unsigned long long acc_r, unsigned long long acc_g,
-                                                  unsigned long long acc_b, uint32_t lane) {
-  uint64_t todo = __ballot(want);
-  while (todo != 0) {
-    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-    const uint32_t pix = (uint32_t)__builtin_amdgcn_readlane((int)accpix, (int)leader);
-    const bool mine = want && accpix == pix;
-    const unsigned long long sr = wave_sum(mine ? acc_r : 0ull);
-    const unsigned long long sg = wave_sum(mine ? acc_g : 0ull);
-    const unsigned long long sb = wave_sum(mine ? acc_b : 0ull);
-    if (lane == leader) {
-      atomicAdd(&accum[3ull * pix + 0], sr);
-      atomicAdd(&accum[3ull * pix + 1], sg);
-      atomicAdd(&accum[3ull * pix + 2], sb);
-    }
-    todo &= ~__ballot(mine);
+                                                  unsigned long long acc_b) {
+  if (want) {
+    atomicAdd(&accum[3ull * accpix + 0], acc_r);
+    atomicAdd(&accum[3ull * accpix + 1], acc_g);
+    atomicAdd(&accum[3ull * accpix + 2], acc_b);
   }
 }
 
@@ -413,7 +405,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       const uint32_t pix_word = pool[8 * 64 + entry];
       const uint32_t pix_local = pix_word & 0x7fffffffu;
       // a lane that moves on to another pixel hands its sums over first
-      wave_flush(P.accum, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
+      flush_sums(P.accum, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b);
       if (take) {
         if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
         o.x = __uint_as_float(pool[0 * 64 + entry]); o.y = __uint_as_float(pool[1 * 64 + entry]);
@@ -509,7 +501,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 #ifdef RTOW_PROFILE_TIMELINE
   if (lane == 0 && wave_id < 16384) g_wave_times[12 * wave_id + 10] = __builtin_amdgcn_s_memrealtime();
 #endif
-  wave_flush(P.accum, accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
+  flush_sums(P.accum, accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b);
   RTOW_PROF_FLUSH();
 #ifdef RTOW_PROFILE_TIMELINE
   if (lane == 0 && wave_id < 16384) {
