@@ -5,9 +5,9 @@
 //                      path ends, so the sphere scan always runs with full wavefronts.  Work is
 //                      handed out in chunks (runs of consecutive paths, pixel-major) from a global
 //                      counter, in sizes that shrink as the frame runs out.  Radiance is summed per lane in
-//                      64-bit fixed point; a lane that moves on to another pixel adds its sums to
-//                      the frame with integer atomics, which makes the image independent of
-//                      scheduling, chunking and GPU count.
+//                      64-bit fixed point; a lane that moves on to another pixel adds its sums
+//                      (through a small per-wave cache in LDS) to the frame with integer atomics,
+//                      which makes the image independent of scheduling, chunking and GPU count.
 //  rtow_resolve_kernel mean + sqrt gamma + clamp + 8-bit quantisation (raytracer.nim:22-28).
 //
 // The sphere scan (hittables.nim:79-88 over hitrecord.nim:55-63) keeps the ray in VGPRs and
@@ -209,19 +209,69 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
 }
 
 // A lane keeps the fixed-point radiance sums of the pixel it is working on in registers (about eight
-// paths in a row belong to the same pixel at spp 500) and hands them to the image when it moves on to
-// another pixel: three 64-bit atomics, result unused.  Integer sums do not depend on the order they
-// arrive in.  (Adding up the lanes of one pixel across the wavefront first - one set of atomics per
-// pixel and wave - cuts the memory traffic tenfold but costs more VALU instructions than it saves:
-// the lanes of a wave change pixel a few at a time, and every such round paid for a full reduction.)
-static __device__ __forceinline__ void flush_sums(unsigned long long* accum, bool want, uint32_t accpix,
-                                                  unsigned long long acc_r, unsigned long long acc_g,
-                                                  unsigned long long acc_b) {
-  if (want) {
-    atomicAdd(&accum[3ull * accpix + 0], acc_r);
-    atomicAdd(&accum[3ull * accpix + 1], acc_g);
-    atomicAdd(&accum[3ull * accpix + 2], acc_b);
+// paths in a row belong to the same pixel at spp 500) and hands them over when it moves on to another
+// pixel.  The lanes of a wave change pixel a few at a time, so the sums of a pixel are collected in a
+// small per-wave cache in LDS first - four direct-mapped slots of three 64-bit words, filled with LDS
+// atomics - and a slot goes to the frame (three 64-bit global atomics) when another pixel claims it
+// or the wave ends: one set of global atomics per pixel and wave instead of one per lane.  Integer
+// sums do not depend on the order they arrive in.  (A shuffle reduction over the lanes of a pixel does
+// the same at ~100 VALU instructions per round; the LDS atomics cost the VALU one instruction each.)
+constexpr uint32_t kSumSlots = 4;
+constexpr uint32_t kSumCacheDwords = 32;   // per wave: kSumSlots * 3 words of 8 bytes, padded to 128 bytes
+constexpr uint32_t kNoPixel = 0xffffffffu;
+typedef unsigned long long __attribute__((address_space(3)))* lds_u64_ptr;
+
+struct SumCache {
+  lds_u64_ptr words;             // this wave's kSumSlots * 3 words
+  uint32_t tags;                 // lane s < kSumSlots: the pixel slot s holds (one VGPR; scalar registers are scarce here)
+};
+
+static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum, const SumCache& c, uint32_t slot,
+                                                       uint32_t pix, uint32_t lane) {
+  // LDS serves one wave's requests in order: the adds of earlier instructions are in the words read here
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 3u) {
+    const unsigned long long v = c.words[3u * slot + lane];
+    c.words[3u * slot + lane] = 0ull;
+    atomicAdd(&accum[3ull * pix + lane], v);
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Must be called by all 64 lanes together; lanes with `want` set hand over (accpix, acc_*).
+static __device__ __forceinline__ void flush_sums(unsigned long long* accum, SumCache& c, bool want, uint32_t accpix,
+                                                  unsigned long long acc_r, unsigned long long acc_g,
+                                                  unsigned long long acc_b, uint32_t lane) {
+  uint64_t todo = __ballot(want);
+  while (todo != 0) {
+    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+    const uint32_t pix = (uint32_t)__builtin_amdgcn_readlane((int)accpix, (int)leader);
+    const uint32_t slot = pix & (kSumSlots - 1u);
+    const uint32_t held = (uint32_t)__builtin_amdgcn_readlane((int)c.tags, (int)slot);
+    if (held != pix) {
+      if (held != kNoPixel) sum_cache_evict(accum, c, slot, held, lane);
+      c.tags = lane == slot ? pix : c.tags;
+    }
+    const bool mine = want && accpix == pix;
+    if (mine) {
+      __hip_atomic_fetch_add(c.words + 3u * slot + 0u, acc_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __hip_atomic_fetch_add(c.words + 3u * slot + 1u, acc_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __hip_atomic_fetch_add(c.words + 3u * slot + 2u, acc_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    todo &= ~__ballot(mine);
+  }
+}
+
+static __device__ __forceinline__ void sum_cache_drain(unsigned long long* accum, SumCache& c, uint32_t lane) {
+  for (uint32_t slot = 0; slot < kSumSlots; ++slot) {
+    const uint32_t held = (uint32_t)__builtin_amdgcn_readlane((int)c.tags, (int)slot);
+    if (held != kNoPixel) sum_cache_evict(accum, c, slot, held, lane);
+  }
+  c.tags = kNoPixel;
 }
 
 // K_LDS: -k per sphere in LDS (tables up to kMaxSpheresKInLds entries).  X_LDS: the records of the
@@ -229,20 +279,29 @@ static __device__ __forceinline__ void flush_sums(unsigned long long* accum, boo
 // round of exact tests then waits for LDS, not for L2.
 template <bool K_LDS, bool X_LDS>
 __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
-  // LDS: candidate stacks [4 waves][kCandDepth][64], path pools [4 waves][kPoolFields][64], then
+  // LDS: candidate stacks [4 waves][kCandDepth][64], path pools [4 waves][kPoolFields][64], sum caches
+  // [4 waves][kSumCacheDwords], then
   // (K_LDS) -k per sphere, then (X_LDS) the exact-test records
   extern __shared__ f4v lds_raw[];
   uint32_t* const stacks = (uint32_t*)lds_raw;
   uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandDepth * 64 + (threadIdx.x >> 6) * (kPoolFields * 64);
-  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64 / 4;
+  constexpr uint32_t kPerWaveDwords = (kCandDepth + kPoolFields) * 64 + kSumCacheDwords;
+  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * kPerWaveDwords / 4;
   const uint32_t lane = threadIdx.x & 63u;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
   CandStack cand;
   cand.slot = stacks + (threadIdx.x >> 6) * (kCandDepth * 64) + lane;
   cand.n = 0;
+  SumCache sums;
+  {
+    uint32_t* const mine = stacks + (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64 + (threadIdx.x >> 6) * kSumCacheDwords;
+    if (lane < kSumCacheDwords) mine[lane] = 0u;   // read back only by this wave, in order
+    sums.words = (lds_u64_ptr)(unsigned long long*)mine;
+    sums.tags = kNoPixel;
+  }
   if (K_LDS) {
     const int n4 = P.n_geom_pad / 4 + 1;
-    f4v* const dst = lds_raw + (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64 / 4;
+    f4v* const dst = lds_raw + (kTraceThreads / 64) * kPerWaveDwords / 4;
     for (int i = threadIdx.x; i < n4; i += kTraceThreads) dst[i] = ((const f4v*)P.geom_nk)[i];
     if (X_LDS) {
       f4v* const xdst = dst + n4;
@@ -405,7 +464,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       const uint32_t pix_word = pool[8 * 64 + entry];
       const uint32_t pix_local = pix_word & 0x7fffffffu;
       // a lane that moves on to another pixel hands its sums over first
-      flush_sums(P.accum, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b);
+      flush_sums(P.accum, sums, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
       if (take) {
         if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
         o.x = __uint_as_float(pool[0 * 64 + entry]); o.y = __uint_as_float(pool[1 * 64 + entry]);
@@ -501,7 +560,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 #ifdef RTOW_PROFILE_TIMELINE
   if (lane == 0 && wave_id < 16384) g_wave_times[12 * wave_id + 10] = __builtin_amdgcn_s_memrealtime();
 #endif
-  flush_sums(P.accum, accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b);
+  flush_sums(P.accum, sums, accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
+  sum_cache_drain(P.accum, sums, lane);
   RTOW_PROF_FLUSH();
 #ifdef RTOW_PROFILE_TIMELINE
   if (lane == 0 && wave_id < 16384) {
@@ -521,7 +581,7 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
   if (i < n_channels) rgb[i] = (uint8_t)quantise_fix(accum[i], spp);
 }
 
-static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64; }
+static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * ((kCandDepth + kPoolFields) * 64 + kSumCacheDwords); }
 static size_t k_lds_bytes(int n_geom_pad) { return stack_lds_bytes() + sizeof(float) * (size_t)(n_geom_pad + 4); }
 static size_t kx_lds_bytes(int n_geom_pad) { return k_lds_bytes(n_geom_pad) + sizeof(float4) * (size_t)n_geom_pad; }
 
