@@ -110,59 +110,99 @@ static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, co
 }
 
 // Spheres that pass the filter are not tested on the spot (only a few lanes of the wave would be
-// busy): each lane pushes the list index onto a private stack in LDS, and the stacks are drained
-// together - every lane runs the exact test on ITS next candidate, fetched from the per-sphere
-// record table - when a stack is about to fill up and at the end of the scan.  The closest-hit rule
-// (smaller t, then larger index) does not depend on the order candidates are offered in.
-struct CandStack {
-  uint32_t* slot;   // LDS: this lane's column of [kCandDepth][64]
-  uint32_t n;
+// busy).  Survivors go onto ONE list per wave in LDS as (lane, list index) words, and the list is
+// worked off by all 64 lanes together - lane L takes entries L, L + 64, ... whoever they belong to:
+// it fetches the owner's ray across the wave (ds_bpermute), runs the exact test and offers the root to
+// the owner's closest-hit word, a sortable 64-bit key in LDS updated with ds_min_u64.  A wave has
+// about 80 survivors per scan, unevenly spread over its lanes: per-lane queues took as many rounds as
+// the longest of them (3.9 on average), the shared list takes total / 64 (mostly 2).
+// The closest-hit rule (smaller t, then larger index) does not depend on the order of the offers.
+typedef unsigned long long __attribute__((address_space(3)))* lds_u64_ptr;
+constexpr uint32_t kListEntries = 512;   // per wave; drained when fewer than 256 (one group, all lanes) are free
+constexpr uint32_t kOwnerShift = 26;     // entry = lane << 26 | list index
+static_assert(kCandWords == (int)kListEntries + 128, "per-wave list + 64 keys");
+
+struct CandList {
+  uint32_t* list;     // LDS: kListEntries words of this wave
+  lds_u64_ptr best;   // LDS: 64 words of this wave, lane L's closest hit so far (hit_key)
+  uint32_t n;         // wave-uniform: entries in the list
+  uint32_t lane;
 };
 
-static __device__ __forceinline__ void cand_push(CandStack& c, bool pass, int j) {
-  // Usually one of a group's four spheres has survivors; a wave-uniform branch skips the other three
+// smaller t first, then the larger list index; id = -1 (nothing hit) loses every tie
+static __device__ __forceinline__ unsigned long long hit_key(float t, int id) {
+  return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)(0x7fffffff - id);
+}
+
+static __device__ __forceinline__ void lds_order() {
+  // one wave's LDS requests are served in order; the compiler only has to keep them in order too
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// wave-uniform control flow; `pass` differs per lane
+static __device__ __forceinline__ void cand_push(CandList& c, bool pass, int j) {
+  // Usually one of a group's four spheres has survivors; the wave-uniform branch skips the other three
   // pushes (instructions issued with an empty execution mask still take their issue slots).
-  if (__ballot(pass) != 0) {
-    if (pass) c.slot[c.n * 64u] = (uint32_t)j;
-    c.n += pass ? 1u : 0u;
+  const uint64_t m = __ballot(pass);
+  if (m != 0) {
+    if (pass) c.list[c.n + lanes_below(m)] = (c.lane << kOwnerShift) | (uint32_t)j;
+    c.n += (uint32_t)__popcll(m);
   }
 }
 
+static __device__ __forceinline__ float from_lane(int byte_index, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_index, __float_as_int(v)));
+}
+
+// Must run with all 64 lanes active (rays are read from their owners' registers).
 template <typename ExactPtr>
-static __device__ __forceinline__ void cand_drain(CandStack& c, ExactPtr exact, f3 o, f3 u,
-                                                  float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
-  for (uint32_t i = 0; __ballot(i < c.n) != 0; ++i) {
+static __device__ __forceinline__ void cand_drain(CandList& c, ExactPtr exact, f3 o, f3 u, float tmin,
+                                                  int prev RTOW_PROF_PARAM) {
+  lds_order();
+  for (uint32_t base = 0; base < c.n; base += 64u) {
     RTOW_COUNT(10, 1);
-    if (i < c.n) {
-      const int j = (int)c.slot[i * 64u];
+    const uint32_t k = base + c.lane;
+    const bool has = k < c.n;
+    const uint32_t entry = c.list[has ? k : 0u];
+    const int owner = (int)((entry >> kOwnerShift) << 2);
+    const int j = (int)(entry & ((1u << kOwnerShift) - 1u));
+    const f3 oo = {from_lane(owner, o.x), from_lane(owner, o.y), from_lane(owner, o.z)};
+    const f3 uu = {from_lane(owner, u.x), from_lane(owner, u.y), from_lane(owner, u.z)};
+    const float tm = from_lane(owner, tmin);
+    const int pv = __builtin_amdgcn_ds_bpermute(owner, prev);
+    if (has) {
       const f4v sp = exact[j];   // (cx, cy, cz, r^2)
-      const float ocx = o.x - sp.x, ocy = o.y - sp.y, ocz = o.z - sp.z;
-      float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
+      const float ocx = oo.x - sp.x, ocy = oo.y - sp.y, ocz = oo.z - sp.z;
+      float b = ocx * uu.x; b = fmaf(ocy, uu.y, b); b = fmaf(ocz, uu.z, b);
       float m = fmaf(-ocx, ocx, sp.w); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
       const float disc = fmaf(b, b, m);
       float t;
-      const bool ok = regular_candidate(b, disc, tmin, j == prev, t);
-      offer(disc >= 0.0f && ok, t, j, best, id);
+      const bool ok = regular_candidate(b, disc, tm, j == pv, t);
+      if (disc >= 0.0f && ok)
+        __hip_atomic_fetch_min(c.best + (entry >> kOwnerShift), hit_key(t, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
   c.n = 0;
+  lds_order();
 }
 
 template <typename ExactPtr>
 static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, int j, ExactPtr exact,
-                                                  CandStack& cand, const ScanRay& r, f3 o, f3 u, float tmin, int prev,
-                                                  float& best, int& id RTOW_PROF_PARAM) {
+                                                  CandList& cand, const ScanRay& r, f3 o, f3 u, float tmin,
+                                                  int prev RTOW_PROF_PARAM) {
   const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, nk.xy, r);
   const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
-  RTOW_COUNT(9, __ballot(mx >= r.threshold) != 0 ? 1 : 0);
-  if (mx >= r.threshold) {
-    RTOW_COUNT(0, 1);
-    if (__ballot(cand.n > (uint32_t)(kCandDepth - 4)) != 0) cand_drain(cand, exact, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+  if (__ballot(mx >= r.threshold) != 0) {   // wave-uniform: the list's fill count stays a scalar
+    RTOW_COUNT(9, 1);
+    RTOW_COUNT(0, mx >= r.threshold ? 1 : 0);
     cand_push(cand, f0.x >= r.threshold, j);
     cand_push(cand, f0.y >= r.threshold, j + 1);
     cand_push(cand, f1.x >= r.threshold, j + 2);
     cand_push(cand, f1.y >= r.threshold, j + 3);
+    if (cand.n > kListEntries - 256u) cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
   }
 }
 
@@ -176,12 +216,15 @@ static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, 
 // the SGPR copy of k (moved to VGPRs first; same arithmetic, two more instructions per group).
 typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 
+// Called by all 64 lanes of the wave; lanes without a path pass live = false and offer nothing.
 template <bool K_LDS, typename ExactPtr>
 static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exact, const f4v* nk_lds,
-                                                    CandStack& cand, int n_groups, float cmax, f3 o, f3 u, float tmin,
-                                                    int prev, float& best, int& id RTOW_PROF_PARAM) {
+                                                    CandList& cand, int n_groups, float cmax, bool live, f3 o, f3 u,
+                                                    float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
-  const ScanRay r = scan_ray(o, u, cmax);
+  ScanRay r = scan_ray(o, u, cmax);
+  if (!live) r.threshold = INFINITY;
+  cand.best[cand.lane] = hit_key(best, id);   // what the binary64 spheres left; read back after the last drain
   f16v ga = geom[0];
   // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
   // immediate offsets.  (Left to itself the compiler keeps the address in an SGPR and copies it to
@@ -194,12 +237,15 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
     const f16v gb = geom[g + 1];
     f4v kb;
     if (K_LDS) kb = nk[1]; else ka = f4v{-ga.s6, -ga.s7, -ga.se, -ga.sf};
-    group_test(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    group_test(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev RTOW_PROF_ARG);
     ga = geom[g + 2];
     if (K_LDS) { ka = nk[2]; nk += 2; } else kb = f4v{-gb.s6, -gb.s7, -gb.se, -gb.sf};
-    group_test(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    group_test(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev RTOW_PROF_ARG);
   }
-  cand_drain(cand, exact, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+  cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
+  const unsigned long long key = cand.best[cand.lane];
+  best = __uint_as_float((uint32_t)(key >> 32));
+  id = 0x7fffffff - (int)(uint32_t)key;
 }
 
 static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -219,7 +265,6 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
 constexpr uint32_t kSumSlots = 4;
 constexpr uint32_t kSumCacheDwords = 32;   // per wave: kSumSlots * 3 words of 8 bytes, padded to 128 bytes
 constexpr uint32_t kNoPixel = 0xffffffffu;
-typedef unsigned long long __attribute__((address_space(3)))* lds_u64_ptr;
 
 struct SumCache {
   lds_u64_ptr words;             // this wave's kSumSlots * 3 words
@@ -279,22 +324,24 @@ static __device__ __forceinline__ void sum_cache_drain(unsigned long long* accum
 // round of exact tests then waits for LDS, not for L2.
 template <bool K_LDS, bool X_LDS>
 __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
-  // LDS: candidate stacks [4 waves][kCandDepth][64], path pools [4 waves][kPoolFields][64], sum caches
+  // LDS: candidate lists + closest-hit keys [4 waves][kCandWords], path pools [4 waves][kPoolFields][64], sum caches
   // [4 waves][kSumCacheDwords], then
   // (K_LDS) -k per sphere, then (X_LDS) the exact-test records
   extern __shared__ f4v lds_raw[];
   uint32_t* const stacks = (uint32_t*)lds_raw;
-  uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandDepth * 64 + (threadIdx.x >> 6) * (kPoolFields * 64);
-  constexpr uint32_t kPerWaveDwords = (kCandDepth + kPoolFields) * 64 + kSumCacheDwords;
+  uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandWords + (threadIdx.x >> 6) * (kPoolFields * 64);
+  constexpr uint32_t kPerWaveDwords = kCandWords + kPoolFields * 64 + kSumCacheDwords;
   const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * kPerWaveDwords / 4;
   const uint32_t lane = threadIdx.x & 63u;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
-  CandStack cand;
-  cand.slot = stacks + (threadIdx.x >> 6) * (kCandDepth * 64) + lane;
+  CandList cand;
+  cand.list = stacks + (threadIdx.x >> 6) * kCandWords;
+  cand.best = (lds_u64_ptr)(unsigned long long*)(cand.list + kListEntries);
   cand.n = 0;
+  cand.lane = lane;
   SumCache sums;
   {
-    uint32_t* const mine = stacks + (kTraceThreads / 64) * (kCandDepth + kPoolFields) * 64 + (threadIdx.x >> 6) * kSumCacheDwords;
+    uint32_t* const mine = stacks + (kTraceThreads / 64) * (kCandWords + kPoolFields * 64) + (threadIdx.x >> 6) * kSumCacheDwords;
     if (lane < kSumCacheDwords) mine[lane] = 0u;   // read back only by this wave, in order
     sums.words = (lds_u64_ptr)(unsigned long long*)mine;
     sums.tags = kNoPixel;
@@ -498,10 +545,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       }
     }
     const unsigned long long t_scan0 = RTOW_CLOCK();
-    if (alive) {
-      if (X_LDS) scan_regular<K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
-      else scan_regular<K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, o, u, tmin, prev, best, id RTOW_PROF_ARG);
-    }
+    // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
+    if (X_LDS) scan_regular<K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    else scan_regular<K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     const unsigned long long t_scan1 = RTOW_CLOCK();
 #ifdef RTOW_PROFILE_COUNTERS
     uint32_t shade_draws = 0;
@@ -581,7 +627,7 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
   if (i < n_channels) rgb[i] = (uint8_t)quantise_fix(accum[i], spp);
 }
 
-static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * ((kCandDepth + kPoolFields) * 64 + kSumCacheDwords); }
+static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * (kCandWords + kPoolFields * 64 + kSumCacheDwords); }
 static size_t k_lds_bytes(int n_geom_pad) { return stack_lds_bytes() + sizeof(float) * (size_t)(n_geom_pad + 4); }
 static size_t kx_lds_bytes(int n_geom_pad) { return k_lds_bytes(n_geom_pad) + sizeof(float4) * (size_t)n_geom_pad; }
 
