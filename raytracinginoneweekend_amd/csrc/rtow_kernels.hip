@@ -161,11 +161,12 @@ template <typename ExactPtr>
 static __device__ __forceinline__ void cand_drain(CandList& c, ExactPtr exact, f3 o, f3 u, float tmin,
                                                   int prev RTOW_PROF_PARAM) {
   lds_order();
-  for (uint32_t base = 0; base < c.n; base += 64u) {
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.n);   // a scalar loop bound
+  for (uint32_t base = 0; base < n; base += 64u) {
     RTOW_COUNT(10, 1);
     const uint32_t k = base + c.lane;
-    const bool has = k < c.n;
-    const uint32_t entry = c.list[has ? k : 0u];
+    const bool has = k < n;
+    const uint32_t entry = c.list[k];   // lanes past the end read into the key words behind the list: unused
     const int owner = (int)((entry >> kOwnerShift) << 2);
     const int j = (int)(entry & ((1u << kOwnerShift) - 1u));
     const f3 oo = {from_lane(owner, o.x), from_lane(owner, o.y), from_lane(owner, o.z)};
@@ -329,19 +330,20 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   // (K_LDS) -k per sphere, then (X_LDS) the exact-test records
   extern __shared__ f4v lds_raw[];
   uint32_t* const stacks = (uint32_t*)lds_raw;
-  uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandWords + (threadIdx.x >> 6) * (kPoolFields * 64);
   constexpr uint32_t kPerWaveDwords = kCandWords + kPoolFields * 64 + kSumCacheDwords;
   const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * kPerWaveDwords / 4;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandWords + wave * (kPoolFields * 64);
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
   CandList cand;
-  cand.list = stacks + (threadIdx.x >> 6) * kCandWords;
+  cand.list = stacks + wave * kCandWords;
   cand.best = (lds_u64_ptr)(unsigned long long*)(cand.list + kListEntries);
   cand.n = 0;
   cand.lane = lane;
   SumCache sums;
   {
-    uint32_t* const mine = stacks + (kTraceThreads / 64) * (kCandWords + kPoolFields * 64) + (threadIdx.x >> 6) * kSumCacheDwords;
+    uint32_t* const mine = stacks + (kTraceThreads / 64) * (kCandWords + kPoolFields * 64) + wave * kSumCacheDwords;
     if (lane < kSumCacheDwords) mine[lane] = 0u;   // read back only by this wave, in order
     sums.words = (lds_u64_ptr)(unsigned long long*)mine;
     sums.tags = kNoPixel;
