@@ -185,13 +185,14 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   HIP_TRY(hipStreamSynchronize(c->stream));  // a render may still be reading the old tables
 
   const int n_pad = ((n + rtow::kGeomPad - 1) / rtow::kGeomPad) * rtow::kGeomPad;
-  // four spheres per 16-float group: cx0 cx1 cy0 cy1 cz0 cz1 k0 k1 | cx2 cx3 cy2 cy3 cz2 cz3 k2 k3
+  // four spheres per 16-float group: cx0 cx1 cy0 cy1 cz0 cz1 | cx2 cx3 cy2 cy3 cz2 cz3 | k0 k1 k2 k3
   // with k = |c|^2 - r^2 (+inf: never passes the filter)
   // plus one all-padding group behind the last one (the scan prefetches past the end)
   const int n_alloc = n_pad + 4;
   std::vector<float> geom((size_t)n_alloc * 4, 0.0f);
   auto geom_at = [&geom](int j, int field) -> float& {
-    return geom[(size_t)(j / 4) * 16 + (size_t)((j % 4) / 2) * 8 + (size_t)field * 2 + (size_t)(j % 2)];
+    if (field == 3) return geom[(size_t)(j / 4) * 16 + 12 + (size_t)(j % 4)];
+    return geom[(size_t)(j / 4) * 16 + (size_t)((j % 4) / 2) * 6 + (size_t)field * 2 + (size_t)(j % 2)];
   };
   std::vector<rtow::SphereShade> shade((size_t)(n > 0 ? n : 1));
   std::vector<rtow::BigSphere> big;

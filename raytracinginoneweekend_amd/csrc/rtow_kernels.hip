@@ -57,6 +57,7 @@ __device__ unsigned long long g_wave_times[12 * 16384];
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f8v __attribute__((ext_vector_type(8)));
 // constant address space: wave-uniform loads from it become s_load_dwordx16 into SGPRs
 typedef const f16v __attribute__((address_space(4)))* geom_ptr;
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -93,9 +94,10 @@ static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
 // discriminant by a few ulps of (|o| + |c|)^2, which `margin` (ScanRay::threshold) covers; a sphere
 // that passes is then tested exactly, so the filter only ever adds work, never hits.
 //
-// The table is stored in groups of four spheres, 16 floats per group, as two packed pairs:
-//   cx0 cx1  cy0 cy1  cz0 cz1  k0 k1 | cx2 cx3  cy2 cy3  cz2 cz3  k2 k3
-// One s_load_dwordx16 brings a group into SGPRs, two groups ahead of its use.  Spheres handled
+// The table is stored in groups of four spheres, 16 floats per group, as two packed pairs and k:
+//   cx0 cx1  cy0 cy1  cz0 cz1 | cx2 cx3  cy2 cy3  cz2 cz3 | k0 k1 k2 k3
+// Scalar loads bring a group into SGPRs, two groups ahead of its use: the first 12 floats when -k
+// comes from LDS (scalar registers are the scarcest resource of this kernel), all 16 otherwise.  Spheres handled
 // elsewhere and the padding carry k = +inf, so they never pass.  r^2 for the exact test comes from
 // a separate array, fetched only when needed.
 static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, const f2v cz, const f2v nk,
@@ -189,12 +191,34 @@ static __device__ __forceinline__ void cand_drain(CandList& c, ExactPtr exact, f
   lds_order();
 }
 
+struct GroupRec {   // centres of four spheres as packed pairs
+  f8v a;            // cx0 cx1 cy0 cy1 cz0 cz1 cx2 cx3
+  f4v b;            // cy2 cy3 cz2 cz3
+};
+
+template <bool K_LDS>
+static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v& nk) {
+  GroupRec r;
+  if (K_LDS) {
+    typedef const f8v __attribute__((address_space(4)))* p8;
+    typedef const f4v __attribute__((address_space(4)))* p4;
+    r.a = *(p8)(geom + g);
+    r.b = *((p4)(geom + g) + 2);
+  } else {
+    const f16v v = geom[g];
+    r.a = v.lo;
+    r.b = f4v{v.s8, v.s9, v.sa, v.sb};
+    nk = f4v{-v.sc, -v.sd, -v.se, -v.sf};
+  }
+  return r;
+}
+
 template <typename ExactPtr>
-static __device__ __forceinline__ void group_test(const f16v grp, const f4v nk, int j, ExactPtr exact,
+static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v nk, int j, ExactPtr exact,
                                                   CandList& cand, const ScanRay& r, f3 o, f3 u, float tmin,
                                                   int prev RTOW_PROF_PARAM) {
-  const f2v f0 = pair_filter(grp.s01, grp.s23, grp.s45, nk.xy, r);
-  const f2v f1 = pair_filter(grp.s89, grp.sab, grp.scd, nk.zw, r);
+  const f2v f0 = pair_filter(grp.a.s01, grp.a.s23, grp.a.s45, nk.xy, r);
+  const f2v f1 = pair_filter(grp.a.s67, grp.b.xy, grp.b.zw, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
   if (__ballot(mx >= r.threshold) != 0) {   // wave-uniform: the list's fill count stays a scalar
     RTOW_COUNT(9, 1);
@@ -226,21 +250,20 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   ScanRay r = scan_ray(o, u, cmax);
   if (!live) r.threshold = INFINITY;
   cand.best[cand.lane] = hit_key(best, id);   // what the binary64 spheres left; read back after the last drain
-  f16v ga = geom[0];
   // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
   // immediate offsets.  (Left to itself the compiler keeps the address in an SGPR and copies it to
   // a VGPR for every read: one more VALU instruction per group.)
   uint32_t nk_addr = K_LDS ? (uint32_t)(uintptr_t)(nk_lds_ptr)nk_lds : 0u;
   asm volatile("" : "+v"(nk_addr));
   nk_lds_ptr nk = (nk_lds_ptr)(uintptr_t)nk_addr;
-  f4v ka = K_LDS ? nk[0] : f4v{0, 0, 0, 0};
+  f4v ka = K_LDS ? nk[0] : f4v{0, 0, 0, 0}, kb = ka;
+  GroupRec ga = load_group<K_LDS>(geom, 0, ka);
   for (int g = 0; g < n_groups; g += 2) {
-    const f16v gb = geom[g + 1];
-    f4v kb;
-    if (K_LDS) kb = nk[1]; else ka = f4v{-ga.s6, -ga.s7, -ga.se, -ga.sf};
+    const GroupRec gb = load_group<K_LDS>(geom, g + 1, kb);
+    if (K_LDS) kb = nk[1];
     group_test(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev RTOW_PROF_ARG);
-    ga = geom[g + 2];
-    if (K_LDS) { ka = nk[2]; nk += 2; } else kb = f4v{-gb.s6, -gb.s7, -gb.se, -gb.sf};
+    ga = load_group<K_LDS>(geom, g + 2, ka);
+    if (K_LDS) { ka = nk[2]; nk += 2; }
     group_test(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev RTOW_PROF_ARG);
   }
   cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
