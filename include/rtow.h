@@ -82,7 +82,8 @@ int rtow_destroy(rtow_ctx* ctx);
  * center_* / radius: Sphere.center, Sphere.radius (hitrecord.nim:11-14; a negative radius is
  * legal and flips the normal, raytracer.nim:72).  kind: RTOW_* per sphere.  albedo_rgb: 3 floats
  * per sphere (ignored for dielectrics).  fuzz: Metal.fuzz.  ir: Dielectric.ir.
- * All pointers are host pointers; the data is copied.  n may be 0 (every ray sees the sky). */
+ * All pointers are host pointers; the data is copied.  n may be 0 (every ray sees the sky) and at
+ * most 2^26 - 16 (RTOW_ERR_INVALID beyond). */
 int rtow_set_scene(rtow_ctx* ctx, int n, const float* center_x, const float* center_y,
                    const float* center_z, const float* radius, const uint8_t* kind,
                    const float* albedo_rgb, const float* fuzz, const float* ir);

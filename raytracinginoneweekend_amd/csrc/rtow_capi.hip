@@ -174,6 +174,7 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
                    const float* ir) {
   if (!c) return fail(RTOW_ERR_INVALID, "rtow_set_scene: ctx is NULL");
   if (n < 0) return fail(RTOW_ERR_INVALID, "rtow_set_scene: n = %d", n);
+  if (n > rtow::kMaxSpheres) return fail(RTOW_ERR_INVALID, "rtow_set_scene: n = %d (at most %d spheres)", n, rtow::kMaxSpheres);
   if (n > 0 && (!cx || !cy || !cz || !radius || !kind || !albedo || !fuzz || !ir))
     return fail(RTOW_ERR_INVALID, "rtow_set_scene: NULL array with n = %d", n);
   for (int j = 0; j < n; ++j) {

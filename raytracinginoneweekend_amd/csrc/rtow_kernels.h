@@ -7,6 +7,7 @@ namespace rtow {
 
 constexpr int kTraceThreads = 256;   // 4 wavefronts per workgroup
 constexpr int kGeomPad = 8;
+constexpr int kMaxSpheres = (1 << 26) - 16;   // list indices travel in 26 bits beside a 6-bit lane number
 constexpr int kCandWords = 640;      // per wave: list of filter survivors awaiting the exact test (512) + closest-hit keys (64 x 8 bytes)
 constexpr int kPoolFields = 9;       // per-wave pool of 64 generated camera rays: o, d, stream, pixel word
 constexpr int kMaxSpheresExactInLds = 512; // up to this many entries the exact-test records sit in LDS too (8 KB)

@@ -123,6 +123,7 @@ typedef unsigned long long __attribute__((address_space(3)))* lds_u64_ptr;
 constexpr uint32_t kListEntries = 512;   // per wave; drained when fewer than 256 (one group, all lanes) are free
 constexpr uint32_t kOwnerShift = 26;     // entry = lane << 26 | list index
 static_assert(kCandWords == (int)kListEntries + 128, "per-wave list + 64 keys");
+static_assert(kMaxSpheres + 16 <= (1 << kOwnerShift), "list index must fit beside the lane number");
 
 struct CandList {
   uint32_t* list;     // LDS: kListEntries words of this wave

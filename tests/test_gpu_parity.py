@@ -490,6 +490,39 @@ def test_random_scenes_bit_exact(oracle):
             assert r.stats()["ray_segments"] == ref[3], f"case {case}: segment count"
 
 
+def test_dense_overlap_many_survivors_per_ray(oracle):
+    """600 spheres that all overlap around one point, of all three materials and both radius signs: a ray
+    through the cluster passes the scan's screen for hundreds of them, so the wave's list of survivors
+    fills up and is worked off many times inside one scan, and closest-hit ties are frequent.  Still
+    GPU == CPU mirror bit for bit."""
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    R = _R()
+    rng = np.random.default_rng(7)
+    n = 600
+    center = rng.normal(0.0, 0.35, (n, 3))
+    radius = rng.uniform(0.8, 1.6, n) * rng.choice([1.0, 1.0, -1.0], n)
+    kind = rng.integers(0, 3, n)
+    albedo = rng.uniform(0.2, 1.0, (n, 3))
+    fuzz = rng.uniform(0.0, 0.6, n)
+    ir = rng.uniform(1.1, 2.0, n)
+    world = {"center_x": center[:, 0], "center_y": center[:, 1], "center_z": center[:, 2], "radius": radius,
+             "kind": kind, "albedo": albedo, "fuzz": fuzz, "ir": ir}
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)  # noqa: E731
+    arr, k = oracle.spheres_from_arrays(f32(center), f32(radius), kind, f32(albedo), f32(fuzz), f32(ir))
+    W, H = 64, 48
+    with R.Renderer(0) as r:
+        r.setWorld(world)
+        for look_from, vfov, spp, depth in (((0.0, 0.5, 6.0), 35.0, 4, 12), ((0.1, 0.0, 0.2), 90.0, 2, 6)):
+            r.setCamera(initCamera(point(*look_from), point(0, 0, 0), vec3(0, 1, 0), vfov=vfov, aspectRatio=W / H,
+                                   aperture=0.0, focusDist=5.0))
+            cam = oracle.book_camera(W / H, look_from=look_from, look_at=(0.0, 0.0, 0.0), vfov=vfov, aperture=0.0, focus=5.0)
+            got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+            ref = oracle.render_mirror32(arr, k, cam, W, H, spp, depth, threads=16)
+            _check_bit_exact(got, ref)
+            assert r.stats()["ray_segments"] == ref[3]
+
+
 def test_progressive_passes_reach_the_single_render_image(gpu_renderer):
     """rtow_render_pass: samples added in passes (3 + 1 + 60 + 436) leave the sums, the pixels, the PPM text
     and the segment total of one 500-sample render; intermediate images are those of renders that
