@@ -273,6 +273,52 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   id = 0x7fffffff - (int)(uint32_t)key;
 }
 
+// The same closest-hit query for a wave that has only a few paths left (the end of a frame, when no
+// work is left to refill the idle lanes): instead of every lane walking the whole table for its own
+// ray, the rays are taken one at a time and the TABLE is spread over the 64 lanes - lane L screens
+// spheres L, L + 64, ... for the ray of the current owner, read from the records in LDS.  The screen
+// is the same arithmetic (filter_value is pair_filter one sphere at a time), survivors go to the same
+// list with the owner's lane number, and the exact tests are shared as always, so the result is the
+// same hit; a wave with m paths pays about m * 100 instructions instead of 2 000.
+// Needs -k and the exact-test records in LDS (tables up to kMaxSpheresExactInLds entries).
+constexpr uint32_t kSparseLanes = 12;
+
+template <typename ExactPtr>
+static __device__ __forceinline__ void scan_sparse(ExactPtr exact, const f4v* nk_lds, CandList& cand, int n_pad,
+                                                   float cmax, bool live, f3 o, f3 u, float tmin, int prev,
+                                                   float& best, int& id RTOW_PROF_PARAM) {
+  typedef const float __attribute__((address_space(3)))* lds_f32_ptr;
+  const lds_f32_ptr nk = (lds_f32_ptr)(const float*)nk_lds;
+  cand.best[cand.lane] = hit_key(best, id);
+  uint64_t todo = __ballot(live);
+  while (todo != 0) {
+    const int owner = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int ob = owner << 2;
+    const f3 oo = {from_lane(ob, o.x), from_lane(ob, o.y), from_lane(ob, o.z)};
+    const f3 uu = {from_lane(ob, u.x), from_lane(ob, u.y), from_lane(ob, u.z)};
+    const FilterRay fr = filter_ray(oo, uu, cmax);
+    for (int j0 = 0; j0 < n_pad; j0 += 64) {
+      const int j = j0 + (int)cand.lane;
+      bool pass = false;
+      if (j < n_pad) {
+        const f4v sp = exact[j];
+        pass = filter_value(sp.x, sp.y, sp.z, -nk[j], uu, fr) >= fr.threshold;   // padding and binary64 spheres: k = +inf
+      }
+      const uint64_t m = __ballot(pass);
+      if (m != 0) {
+        if (pass) cand.list[cand.n + lanes_below(m)] = ((uint32_t)owner << kOwnerShift) | (uint32_t)j;
+        cand.n += (uint32_t)__popcll(m);
+        if (cand.n > kListEntries - 64u) cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
+      }
+    }
+  }
+  cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
+  const unsigned long long key = cand.best[cand.lane];
+  best = __uint_as_float((uint32_t)(key >> 32));
+  id = 0x7fffffff - (int)(uint32_t)key;
+}
+
 static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -572,7 +618,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     }
     const unsigned long long t_scan0 = RTOW_CLOCK();
     // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
-    if (X_LDS) scan_regular<K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    if (X_LDS && exhausted && (uint32_t)__popcll(__ballot(alive)) <= kSparseLanes)
+      scan_sparse(exact_lds, nk_lds, cand, P.n_geom_pad, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
+    else if (X_LDS) scan_regular<K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     else scan_regular<K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
     const unsigned long long t_scan1 = RTOW_CLOCK();
 #ifdef RTOW_PROFILE_COUNTERS

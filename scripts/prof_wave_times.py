@@ -15,6 +15,8 @@ n = 6144
 buf = (C.c_ulonglong * (12 * n))()
 assert L.rtow_debug_wave_times(buf, n) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(n, 12).astype(np.float64)
+t = t[t[:, 0] > 0]   # waves that ran (the grid is CUs x resident workgroups x 4)
+print(f"{len(t)} waves")
 live_at_dry, it_dry, it_end = t[:, 3], t[:, 4], t[:, 5]
 raw = t.copy()
 t = t[:, :3] / 100.0  # microseconds
