@@ -33,11 +33,11 @@ proc renderGpu*(img: Image, f: string, world: var HittablesList, camera: Camera,
                        addr albedo[0], addr fuzz[0], addr ir[0]), "rtow_set_scene"
   var cam = camera.flatten()              # proc flatten*(c: Camera): RtowCamera, added to camera.nim
   check rtow_set_camera(ctx, addr cam), "rtow_set_camera"
-  var rgb = newSeq[uint8](img.width * img.height * 3)
+  # the image stays in the context; the P3 text of raytracer.nim:28,35 is composed on the device
   check rtow_render(ctx, img.width.cint, img.height.cint, samplesPerPixel.cint, maxDepth.cint, seed,
-                    nil, img.height.cint, addr rgb[0], nil, nil), "rtow_render"
-  var o = open(f, fmWrite)
-  o.write(&"P3\n{img.width} {img.height}\n255\n")
-  for p in 0 ..< img.width * img.height:
-    o.write(&"{rgb[3*p]} {rgb[3*p+1]} {rgb[3*p+2]}\n")
-  o.close()
+                    nil, img.height.cint, nil, nil, nil), "rtow_render"
+  var length: uint64
+  check rtow_format_ppm(ctx, 0, nil, 0, addr length), "rtow_format_ppm (length)"
+  var text = newString(length.int)
+  check rtow_format_ppm(ctx, 0, text.cstring, length, addr length), "rtow_format_ppm"
+  writeFile(f, text)
