@@ -218,7 +218,8 @@ def main():
         achieved = serial[-1]["ray_segments"] * flop_per_segment / avg_trace_s / 1e12
         paths = width * height * spp
         out = {
-            "metric": "Mrays/sec (ray segments = world.hit queries) book-1 final scene 1200x800 spp500 depth50",
+            "metric": "Mrays/sec (ray segments = world.hit queries) book-1 final scene 1200x800 spp500 depth50"
+                      + ("" if args.workload == "C2" and not args.spp else f" -- NOT the headline configuration: see config.workload"),
             "value": segments / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
