@@ -479,8 +479,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         }
         unsigned long long first = 0;
         if (lane == 0) first = atomicAdd(P.path_counter, (unsigned long long)want);
-        first = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(first >> 32)) << 32) |
-                __builtin_amdgcn_readfirstlane((uint32_t)first);
+        // (the builtin returns int: widen through uint32_t, or a low word >= 2^31 sign-extends over the high word)
+        first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(first >> 32)) << 32) |
+                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
         if (first >= P.total_paths) {
 #ifdef RTOW_PROFILE_TIMELINE
           {

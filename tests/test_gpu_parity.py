@@ -523,6 +523,28 @@ def test_dense_overlap_many_survivors_per_ray(oracle):
             assert r.stats()["ray_segments"] == ref[3]
 
 
+def test_more_than_2_to_32_paths_in_one_launch():
+    """Path indices are 64-bit: a launch of 4.4e9 paths (past 2^32; its two half passes each past 2^31)
+    traces every one of them.  An empty world keeps it cheap - one segment per path, so the segment
+    count must equal the path count exactly - and the sums of the whole launch must equal the sums of
+    the two half passes, which cover different index ranges of the same streams."""
+    R = _R()
+    W, H, spp = 2048, 1024, 2100
+    assert W * H * spp > 2 ** 32 and W * H * (spp // 2) > 2 ** 31
+    from raytracinginoneweekend_amd.hittables import initHittables
+    with R.Renderer(0) as r:
+        r.setWorld(initHittables(0))
+        r.setCamera(R.bookCamera(W / H))
+        whole = r.renderRows(W, H, spp, 50, want_accum=True)
+        assert r.stats()["ray_segments"] == W * H * spp
+        r.renderPass(W, H, 0, spp // 2, 50)
+        r.sync()
+        assert r.stats()["ray_segments"] == W * H * (spp // 2)
+        r.renderPass(W, H, spp // 2, spp - spp // 2, 50)
+        rgb, acc = r.readImage(want_accum=True)
+        assert (acc == whole[1]).all() and (rgb == whole[0]).all()
+
+
 def test_progressive_passes_reach_the_single_render_image(gpu_renderer):
     """rtow_render_pass: samples added in passes (3 + 1 + 60 + 436) leave the sums, the pixels, the PPM text
     and the segment total of one 500-sample render; intermediate images are those of renders that
