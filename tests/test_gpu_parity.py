@@ -545,6 +545,38 @@ def test_more_than_2_to_32_paths_in_one_launch():
         assert (acc == whole[1]).all() and (rgb == whole[0]).all()
 
 
+def test_one_context_per_thread_renders_concurrently(gpu_renderer):
+    """The library keeps no global mutable state: four host threads, each with its own context on the
+    same GPU, render different sample counts at the same time and get what a lone context gets."""
+    import threading
+    R = _R()
+    W, H = 160, 100
+    jobs = [(3, 50), (8, 50), (17, 6), (40, 50)]
+    gpu_renderer.setWorld(R.randomScene())
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    alone = [gpu_renderer.renderRows(W, H, spp, depth, want_accum=True)[1] for spp, depth in jobs]
+    got, errors = [None] * len(jobs), []
+
+    def work(k):
+        try:
+            with R.Renderer(0) as r:
+                r.setWorld(R.randomScene())
+                r.setCamera(R.bookCamera(W / H))
+                for _ in range(5):
+                    got[k] = r.renderRows(W, H, jobs[k][0], jobs[k][1], want_accum=True)[1]
+        except Exception as exc:  # noqa: BLE001 (reported below, in the main thread)
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(len(jobs)):
+        assert (got[k] == alone[k]).all(), f"job {k}"
+
+
 def test_progressive_passes_reach_the_single_render_image(gpu_renderer):
     """rtow_render_pass: samples added in passes (3 + 1 + 60 + 436) leave the sums, the pixels, the PPM text
     and the segment total of one 500-sample render; intermediate images are those of renders that
