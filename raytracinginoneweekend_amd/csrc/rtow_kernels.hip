@@ -117,7 +117,7 @@ static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, co
 // it fetches the owner's ray across the wave (ds_bpermute), runs the exact test and offers the root to
 // the owner's closest-hit word, a sortable 64-bit key in LDS updated with ds_min_u64.  A wave has
 // about 80 survivors per scan, unevenly spread over its lanes: per-lane queues took as many rounds as
-// the longest of them (3.9 on average), the shared list takes total / 64 (mostly 2).
+// the longest of them (3.9 on average), the shared list takes total / 64 (1.5 on average).
 // The closest-hit rule (smaller t, then larger index) does not depend on the order of the offers.
 typedef unsigned long long __attribute__((address_space(3)))* lds_u64_ptr;
 constexpr uint32_t kListEntries = 512;   // per wave; drained when fewer than 256 (one group, all lanes) are free
