@@ -322,8 +322,19 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth; p.sample_base = (uint32_t)first_sample;
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
   p.rows = rows ? (const int32_t*)c->rows.p : nullptr; p.n_rows = n_rows;
-  p.chunk_max = 512;
-  p.chunk_min = 64; p.total_paths = total_paths;
+  // Measured (scripts/sweep_chunks.py): chunks of 192-256 paths beat 512 shrinking to 64 - by 0.5 % on the
+  // full frame and 4 % on a 1/8 share, where the end of the frame weighs more - and 128 or less pay for
+  // the chunk-to-pixel arithmetic (about 250 instructions per chunk).
+  p.chunk_max = 256;
+  p.chunk_min = 192; p.total_paths = total_paths;
+  if (const char* e = getenv("RTOW_CHUNK_MAX")) {  // experiments only: multiples of 64
+    const int v = atoi(e);
+    if (v >= 64 && v <= 65536 && v % 64 == 0) p.chunk_max = (uint32_t)v;
+  }
+  if (const char* e = getenv("RTOW_CHUNK_MIN")) {
+    const int v = atoi(e);
+    if (v >= 64 && (uint32_t)v <= p.chunk_max && v % 64 == 0) p.chunk_min = (uint32_t)v;
+  }
   p.inv_spp = (uint32_t)((0x100000000ull + (uint64_t)spp - 1) / (uint64_t)spp);
   p.seg_counter = (unsigned long long*)c->counters.p;
   p.path_counter = (unsigned long long*)((char*)c->counters.p + 8);
