@@ -3,17 +3,20 @@ import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracinginoneweekend_amd import multigpu, raytracer as R
-r = R.Renderer(0); r.setWorld(R.randomScene()); r.setCamera(R.bookCamera(1.5))
+wl = sys.argv[1] if len(sys.argv) > 1 else 'C2'
+scene = {'C2': lambda: R.randomScene(), 'C3': lambda: R.randomScene(lambertBelow=0.0, metalBelow=0.5), 'C5': lambda: R.randomScene(halfExtent=50)}[wl]()
+spp_full, spp_share = (250, 500) if wl != 'C5' else (32, 64)
+r = R.Renderer(0); r.setWorld(scene); r.setCamera(R.bookCamera(1.5))
 r.renderAsync(1200, 800, 64, 50); r.sync()
 share = multigpu.tile_rows(800, 8, 0, 4)
-combos = [(512, 64), (256, 256), (192, 192), (128, 128), (64, 64), (192, 128), (256, 128), (320, 320)]
+combos = [(512, 64), (256, 192), (256, 256), (192, 192), (128, 128), (512, 256), (1024, 256)]
 res = {c: ([], []) for c in combos}
 import random
 random.seed(1)
-for _ in range(9):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 9):
     for cmax, cmin in random.sample(combos, len(combos)):
         os.environ["RTOW_CHUNK_MAX"], os.environ["RTOW_CHUNK_MIN"] = str(cmax), str(cmin)
-        r.renderAsync(1200, 800, 250, 50); r.sync(); res[(cmax, cmin)][0].append(r.stats()["trace_ms"])
-        r.renderAsync(1200, 800, 500, 50, rows=share); r.sync(); res[(cmax, cmin)][1].append(r.stats()["trace_ms"])
+        r.renderAsync(1200, 800, spp_full, 50); r.sync(); res[(cmax, cmin)][0].append(r.stats()["trace_ms"])
+        r.renderAsync(1200, 800, spp_share, 50, rows=share); r.sync(); res[(cmax, cmin)][1].append(r.stats()["trace_ms"])
 for c in combos:
-    print(f"chunk max {c[0]:5d} min {c[1]:4d}: full spp 250 {statistics.median(res[c][0]):8.3f} ms   1/8 share spp 500 {statistics.median(res[c][1]):8.3f} ms")
+    print(f"chunk max {c[0]:5d} min {c[1]:4d}: full {statistics.median(res[c][0]):8.3f} ms   1/8 share {statistics.median(res[c][1]):8.3f} ms")
