@@ -102,6 +102,10 @@ def lib():
     return _lib
 
 
-def check(status):
+def check(status, library=None):
+    """Raise RtowError for a negative status.  `library` is the build whose call returned it: the
+    message is thread-local state of THAT shared object (a Renderer may run on an alternative build
+    loaded with load(path))."""
     if status != 0:
-        raise RtowError(status, lib().rtow_last_error().decode("utf-8", "replace"))
+        L = library if library is not None else lib()
+        raise RtowError(status, L.rtow_last_error().decode("utf-8", "replace"))

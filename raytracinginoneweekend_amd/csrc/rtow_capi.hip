@@ -70,6 +70,7 @@ struct rtow_ctx {
   DevBuf ppm_len, ppm_off, ppm_text;          // device-side PPM text of the last image (rtow_format_ppm)
   uint64_t ppm_bytes = 0;                     // length of that text, 0 = not composed yet
   bool image_in_workspace = false;            // the last render left its 8-bit image in `rgb`
+  bool sums_in_workspace = false;             // ... and its radiance sums in `accum`
   DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
   uint64_t* host_counters = nullptr;          // pinned, 16 bytes
   char* staging[2] = {nullptr, nullptr};      // pinned, kStagingBytes each: large device-to-host copies go through them
@@ -169,9 +170,29 @@ int rtow_destroy(rtow_ctx* c) {
   return RTOW_OK;
 }
 
+static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
+                          const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
+                          const float* ir);
+
 int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
                    const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
                    const float* ir) {
+  // the tables are staged in std::vector: an allocation failure must come back as a status, not unwind
+  // through the C boundary
+  try {
+    return set_scene_impl(c, n, cx, cy, cz, radius, kind, albedo, fuzz, ir);
+  } catch (const std::bad_alloc&) {
+    return fail(RTOW_ERR_NOMEM, "rtow_set_scene: out of host memory staging %d spheres", n);
+  } catch (...) {
+    return fail(RTOW_ERR_INVALID, "rtow_set_scene: unexpected exception");
+  }
+}
+
+}  // extern "C"
+
+static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
+                          const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
+                          const float* ir) {
   if (!c) return fail(RTOW_ERR_INVALID, "rtow_set_scene: ctx is NULL");
   if (n < 0) return fail(RTOW_ERR_INVALID, "rtow_set_scene: n = %d", n);
   if (n > rtow::kMaxSpheres) return fail(RTOW_ERR_INVALID, "rtow_set_scene: n = %d (at most %d spheres)", n, rtow::kMaxSpheres);
@@ -254,6 +275,8 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   return RTOW_OK;
 }
 
+extern "C" {
+
 int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
   if (!c || !cam) return fail(RTOW_ERR_INVALID, "rtow_set_camera: NULL argument");
   auto v3 = [](const float* p) { rtow::f3 r = {p[0], p[1], p[2]}; return r; };
@@ -263,6 +286,72 @@ int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
   c->have_camera = true;
   c->samples_done = 0;              // likewise for the previous camera
   c->last_row_list_valid = false;
+  return RTOW_OK;
+}
+
+// where one frame's kernels read their row list and keep their sums, counters and pixels
+struct FrameTargets {
+  const int32_t* rows_dev = nullptr;      // device copy of rows[], or nullptr for rows 0..n_rows-1
+  unsigned long long* accum = nullptr;    // n_rows*w*3 sums
+  unsigned char* counters = nullptr;      // 16 bytes: segment count, next path
+  int32_t* hit_id = nullptr;              // n_rows*w, or nullptr
+  uint8_t* rgb = nullptr;                 // n_rows*w*3
+};
+
+// clear + trace + resolve + counter read-back on the context's stream; allocates nothing
+static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed, int first_sample, int n_rows,
+                        const FrameTargets& t) {
+  const uint64_t n_pixels = (uint64_t)n_rows * (uint64_t)w;
+  const uint64_t total_paths = n_pixels * (uint64_t)spp;
+  rtow::TraceParams p;
+  p.cam = c->cam;
+  p.geom = (const float*)c->geom.p; p.geom_exact = (const float4*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
+  p.cmax = c->cmax;
+  p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
+  p.shade = (const rtow::SphereShade*)c->shade.p;
+  p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth; p.sample_base = (uint32_t)first_sample;
+  p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+  p.rows = t.rows_dev; p.n_rows = n_rows;
+  // Measured (scripts/sweep_chunks.py): chunks of 192-256 paths beat 512 shrinking to 64 - by 0.5 % on the
+  // full frame and 4 % on a 1/8 share, where the end of the frame weighs more - and 128 or less pay for
+  // the chunk-to-pixel arithmetic (about 250 instructions per chunk).
+  p.chunk_max = 256;
+  p.chunk_min = 192; p.total_paths = total_paths;
+  if (const char* e = getenv("RTOW_CHUNK_MAX")) {  // experiments only: multiples of 64
+    const int v = atoi(e);
+    if (v >= 64 && v <= 65536 && v % 64 == 0) p.chunk_max = (uint32_t)v;
+  }
+  if (const char* e = getenv("RTOW_CHUNK_MIN")) {
+    const int v = atoi(e);
+    if (v >= 64 && (uint32_t)v <= p.chunk_max && v % 64 == 0) p.chunk_min = (uint32_t)v;
+  }
+  p.inv_spp = (uint32_t)((0x100000000ull + (uint64_t)spp - 1) / (uint64_t)spp);
+  p.seg_counter = (unsigned long long*)t.counters;
+  p.path_counter = (unsigned long long*)(t.counters + 8);
+  p.accum = t.accum;
+  p.hit_id = t.hit_id;
+
+  const uint64_t waves_needed = (total_paths + 63) / 64;
+  int grid = c->n_cu * c->blocks_per_cu;
+  const uint64_t blocks_needed = (waves_needed + (rtow::kTraceThreads / 64) - 1) / (rtow::kTraceThreads / 64);
+  if ((uint64_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
+  p.n_waves = (uint32_t)grid * (rtow::kTraceThreads / 64);
+
+  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(hipMemsetAsync(t.counters, 0, 16, c->stream));
+  if (first_sample == 0 && n_pixels) HIP_TRY(hipMemsetAsync(t.accum, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
+  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+  if (n_pixels) rtow::launch_trace(p, grid, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+  rtow::launch_resolve(t.accum, t.rgb, (uint32_t)(3 * n_pixels), first_sample + spp, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+  HIP_TRY(hipMemcpyAsync(c->host_counters, t.counters, 16, hipMemcpyDeviceToHost, c->stream));
+  c->pending = true;
+  c->ppm_bytes = 0;
+  c->last_w = w; c->last_h = h; c->last_spp = spp; c->last_rows = n_rows;
+  c->last_seed = seed;
   return RTOW_OK;
 }
 
@@ -297,74 +386,41 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   HIP_TRY(hipSetDevice(c->device));
   if (c->pending) HIP_TRY(hipStreamSynchronize(c->stream));
 
-  const uint64_t total_paths = n_pixels * (uint64_t)spp;
-
-  HIP_TRY(c->accum.reserve(sizeof(unsigned long long) * 3 * (n_pixels ? n_pixels : 1)));
-  HIP_TRY(c->rgb.reserve(3 * (n_pixels ? n_pixels : 1)));
-  if (want_hit_id) HIP_TRY(c->hit_id.reserve(sizeof(int32_t) * (n_pixels ? n_pixels : 1)));
-  if (first_sample == 0) {
-    if (rows) c->last_row_list.assign(rows, rows + n_rows); else c->last_row_list.clear();
-    c->last_row_list_valid = true;
+  try {
+    if (first_sample == 0) {
+      std::vector<int32_t> list;
+      if (rows) list.assign(rows, rows + n_rows);
+      c->last_row_list.swap(list);      // nothing below this line throws: the image state stays consistent
+      c->last_row_list_valid = true;
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(RTOW_ERR_NOMEM, "render: out of host memory for %d row indices", n_rows);
   }
-  if (rows) {
-    // uploaded from the context's own copy: the caller may release rows[] as soon as this call returns
-    HIP_TRY(c->rows.reserve(sizeof(int32_t) * (size_t)(n_rows ? n_rows : 1)));
-    HIP_TRY(hipMemcpyAsync(c->rows.p, c->last_row_list.data(), sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice,
-                           c->stream));
-  }
+  const int rc0 = [&]() -> int {
+    HIP_TRY(c->accum.reserve(sizeof(unsigned long long) * 3 * (n_pixels ? n_pixels : 1)));
+    HIP_TRY(c->rgb.reserve(3 * (n_pixels ? n_pixels : 1)));
+    if (want_hit_id) HIP_TRY(c->hit_id.reserve(sizeof(int32_t) * (n_pixels ? n_pixels : 1)));
+    if (rows) {
+      // uploaded from the context's own copy: the caller may release rows[] as soon as this call returns
+      HIP_TRY(c->rows.reserve(sizeof(int32_t) * (size_t)(n_rows ? n_rows : 1)));
+      HIP_TRY(hipMemcpyAsync(c->rows.p, c->last_row_list.data(), sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice,
+                             c->stream));
+    }
+    return RTOW_OK;
+  }();
+  if (rc0 != RTOW_OK) { c->samples_done = 0; c->last_row_list_valid = false; return rc0; }
 
-  rtow::TraceParams p;
-  p.cam = c->cam;
-  p.geom = (const float*)c->geom.p; p.geom_exact = (const float4*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
-  p.cmax = c->cmax;
-  p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
-  p.shade = (const rtow::SphereShade*)c->shade.p;
-  p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth; p.sample_base = (uint32_t)first_sample;
-  p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
-  p.rows = rows ? (const int32_t*)c->rows.p : nullptr; p.n_rows = n_rows;
-  // Measured (scripts/sweep_chunks.py): chunks of 192-256 paths beat 512 shrinking to 64 - by 0.5 % on the
-  // full frame and 4 % on a 1/8 share, where the end of the frame weighs more - and 128 or less pay for
-  // the chunk-to-pixel arithmetic (about 250 instructions per chunk).
-  p.chunk_max = 256;
-  p.chunk_min = 192; p.total_paths = total_paths;
-  if (const char* e = getenv("RTOW_CHUNK_MAX")) {  // experiments only: multiples of 64
-    const int v = atoi(e);
-    if (v >= 64 && v <= 65536 && v % 64 == 0) p.chunk_max = (uint32_t)v;
-  }
-  if (const char* e = getenv("RTOW_CHUNK_MIN")) {
-    const int v = atoi(e);
-    if (v >= 64 && (uint32_t)v <= p.chunk_max && v % 64 == 0) p.chunk_min = (uint32_t)v;
-  }
-  p.inv_spp = (uint32_t)((0x100000000ull + (uint64_t)spp - 1) / (uint64_t)spp);
-  p.seg_counter = (unsigned long long*)c->counters.p;
-  p.path_counter = (unsigned long long*)((char*)c->counters.p + 8);
-  p.accum = (unsigned long long*)c->accum.p;
-  p.hit_id = want_hit_id ? (int32_t*)c->hit_id.p : nullptr;
-
-  uint8_t* rgb = rgb_dev ? (uint8_t*)rgb_dev : (uint8_t*)c->rgb.p;
-  const uint64_t waves_needed = (total_paths + 63) / 64;
-  int grid = c->n_cu * c->blocks_per_cu;
-  const uint64_t blocks_needed = (waves_needed + (rtow::kTraceThreads / 64) - 1) / (rtow::kTraceThreads / 64);
-  if ((uint64_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
-  p.n_waves = (uint32_t)grid * (rtow::kTraceThreads / 64);
-
-  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(hipMemsetAsync(c->counters.p, 0, 16, c->stream));
-  if (first_sample == 0) HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
-  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  if (n_pixels) rtow::launch_trace(p, grid, c->stream);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-  rtow::launch_resolve((const unsigned long long*)c->accum.p, rgb, (uint32_t)(3 * n_pixels), first_sample + spp, c->stream);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  HIP_TRY(hipMemcpyAsync(c->host_counters, c->counters.p, 16, hipMemcpyDeviceToHost, c->stream));
-  c->pending = true;
+  FrameTargets t;
+  t.rows_dev = rows ? (const int32_t*)c->rows.p : nullptr;
+  t.accum = (unsigned long long*)c->accum.p;
+  t.counters = (unsigned char*)c->counters.p;
+  t.hit_id = want_hit_id ? (int32_t*)c->hit_id.p : nullptr;
+  t.rgb = rgb_dev ? (uint8_t*)rgb_dev : (uint8_t*)c->rgb.p;
+  const int rc = launch_frame(c, w, h, spp, max_depth, seed, first_sample, n_rows, t);
+  if (rc != RTOW_OK) { c->samples_done = 0; c->last_row_list_valid = false; return rc; }
   c->image_in_workspace = rgb_dev == nullptr;
-  c->ppm_bytes = 0;
-  c->last_w = w; c->last_h = h; c->last_spp = spp; c->last_rows = n_rows;
+  c->sums_in_workspace = true;
   c->samples_done = first_sample + spp;
-  c->last_seed = seed;
   return RTOW_OK;
 }
 
@@ -399,6 +455,8 @@ int rtow_read_image(rtow_ctx* c, uint8_t* rgb_out, uint64_t* accum_out) {
   if (c->last_w == 0) return fail(RTOW_ERR_STATE, "rtow_read_image: nothing has been rendered on this context");
   if (rgb_out && !c->image_in_workspace)
     return fail(RTOW_ERR_STATE, "rtow_read_image: the last render wrote its image to the caller's device buffer");
+  if (accum_out && !c->sums_in_workspace)
+    return fail(RTOW_ERR_STATE, "rtow_read_image: the last render kept its sums outside the context (rtow_render_noalloc)");
   const int rc = rtow_sync(c);
   if (rc != RTOW_OK) return rc;
   const size_t n_pixels = (size_t)c->last_rows * (size_t)c->last_w;
@@ -423,8 +481,25 @@ int rtow_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed
   return RTOW_OK;
 }
 
+static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth, uint64_t seed,
+                             int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out);
+
 int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth, uint64_t seed,
                       int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out) {
+  try {
+    return render_multi_impl(ctxs, n_ctx, w, h, spp, max_depth, seed, tile_rows, rgb_out, ray_segments_out);
+  } catch (const std::bad_alloc&) {
+    if (ctxs) for (int k = 0; k < n_ctx; ++k) if (ctxs[k]) (void)rtow_sync(ctxs[k]);
+    return fail(RTOW_ERR_NOMEM, "rtow_render_multi: out of host memory");
+  } catch (...) {
+    return fail(RTOW_ERR_INVALID, "rtow_render_multi: unexpected exception");
+  }
+}
+
+}  // extern "C"
+
+static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth, uint64_t seed,
+                             int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out) {
   if (!ctxs || n_ctx < 1) return fail(RTOW_ERR_INVALID, "rtow_render_multi: no contexts");
   if (tile_rows < 1) return fail(RTOW_ERR_INVALID, "rtow_render_multi: tile_rows = %d", tile_rows);
   if (h < 2) return fail(RTOW_ERR_INVALID, "render: image %dx%d (width and height must be >= 2)", w, h);
@@ -470,6 +545,8 @@ int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, i
   if (ray_segments_out) *ray_segments_out = segments;
   return RTOW_OK;
 }
+
+extern "C" {
 
 int rtow_format_ppm(rtow_ctx* c, int binary, char* out, uint64_t capacity, uint64_t* length) {
   if (!c) return fail(RTOW_ERR_INVALID, "rtow_format_ppm: ctx is NULL");

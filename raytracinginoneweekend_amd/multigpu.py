@@ -60,6 +60,13 @@ class TileGatherer:
         import torch
         self.height, self.width, self.world, self.rank, self.tile = height, width, world_size, rank, tile
         self.group, self.dst = group, dst
+        # The collective is chosen once, from the backend: gloo has no flat all_gather_into_tensor.
+        # Errors of the chosen collective propagate - a rank that fell back to another collective
+        # after a failure would leave its peers waiting in the first one.
+        self.flat = True
+        if world_size > 1:
+            import torch.distributed as dist
+            self.flat = dist.get_backend(group) != "gloo"
         self.rows = tile_rows(height, world_size, rank, tile)
         self.n_pad = padded_rows(height, world_size, tile)
         self.local = torch.zeros((self.n_pad, width, 3), dtype=torch.uint8, device=device)
@@ -79,9 +86,9 @@ class TileGatherer:
         import torch.distributed as dist
         if self.world == 1:
             return self.local[: len(self.rows)]
-        try:
+        if self.flat:
             dist.all_gather_into_tensor(self.recv.view(-1), self.local.view(-1), group=self.group)
-        except (RuntimeError, NotImplementedError):  # backends without the flat form (gloo)
+        else:
             dist.all_gather(list(self.recv.unbind(0)), self.local, group=self.group)
         if self.rank != self.dst:
             return None

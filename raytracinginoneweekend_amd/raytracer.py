@@ -27,9 +27,13 @@ class Renderer:
     def __init__(self, device=0, lib=None):
         self._lib = lib if lib is not None else _lib.lib()
         h = C.c_void_p()
-        _lib.check(self._lib.rtow_create(int(device), C.byref(h)))
+        self._check(self._lib.rtow_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self._last_shape = None   # (n_rows, width) of the last render enqueued through this object
+
+    def _check(self, status):
+        _lib.check(status, self._lib)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -59,19 +63,22 @@ class Renderer:
         if not (len(cx) == len(cy) == len(cz) == len(kind) == len(fuzz) == len(ir) == n and albedo.shape == (n, 3)):
             raise ValueError("setWorld: arrays of unequal length")
         p = lambda a: a.ctypes.data if n else None  # noqa: E731
-        _lib.check(self._lib.rtow_set_scene(self._h, n, p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo), p(fuzz), p(ir)))
+        self._check(self._lib.rtow_set_scene(self._h, n, p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo), p(fuzz), p(ir)))
         self.n_spheres = n
 
     def setCamera(self, camera):
         s = camera.to_struct() if isinstance(camera, Camera) else camera
-        _lib.check(self._lib.rtow_set_camera(self._h, C.byref(s)))
+        self._check(self._lib.rtow_set_camera(self._h, C.byref(s)))
 
     @staticmethod
     def _rows(rows, height):
         if rows is None:
             return None, height, None
         r = np.ascontiguousarray(rows, dtype=np.int32)
-        return r, len(r), (r.ctypes.data if len(r) else None)
+        if len(r) == 0:   # an empty row list is legal; the ABI wants a non-NULL pointer to tell it from "all rows"
+            r = np.zeros(1, np.int32)
+            return r, 0, r.ctypes.data
+        return r, len(r), r.ctypes.data
 
     def renderRows(self, width, height, samplesPerPixel, maxDepth, seed=RENDER_SEED, rows=None,
                    want_accum=False, want_hit_id=False):
@@ -80,61 +87,62 @@ class Renderer:
         rgb = np.empty((n_rows, width, 3), np.uint8)
         acc = np.empty((n_rows, width, 3), np.uint64) if want_accum else None
         hid = np.empty((n_rows, width), np.int32) if want_hit_id else None
-        if rows is not None and n_rows == 0:
-            rows_p = np.zeros(1, np.int32).ctypes.data
-        _lib.check(self._lib.rtow_render(
+        self._check(self._lib.rtow_render(
             self._h, width, height, samplesPerPixel, maxDepth, seed, rows_p, n_rows,
             rgb.ctypes.data if rgb.size else None,
             acc.ctypes.data if acc is not None and acc.size else None,
             hid.ctypes.data if hid is not None and hid.size else None))
+        self._last_shape = (n_rows, width)
         return rgb, acc, hid
 
     def renderAsync(self, width, height, samplesPerPixel, maxDepth, seed=RENDER_SEED, rows=None, rgb_dev=None):
         """Enqueue a render whose 8-bit image stays on the device (rgb_dev: device address or None)."""
         keep, n_rows, rows_p = self._rows(rows, height)
-        _lib.check(self._lib.rtow_render_async(self._h, width, height, samplesPerPixel, maxDepth, seed,
+        self._check(self._lib.rtow_render_async(self._h, width, height, samplesPerPixel, maxDepth, seed,
                                                rows_p, n_rows, rgb_dev))
+        self._last_shape = (n_rows, width)
 
     def renderPass(self, width, height, firstSample, nSamples, maxDepth, seed=RENDER_SEED, rows=None, rgb_dev=None):
         """Progressive refinement: add samples firstSample .. firstSample+nSamples-1 of every pixel to the
         image this context holds (firstSample = 0 starts one).  Asynchronous."""
         keep, n_rows, rows_p = self._rows(rows, height)
-        if rows is not None and n_rows == 0:
-            rows_p = np.zeros(1, np.int32).ctypes.data
-        _lib.check(self._lib.rtow_render_pass(self._h, width, height, firstSample, nSamples, maxDepth, seed,
+        self._check(self._lib.rtow_render_pass(self._h, width, height, firstSample, nSamples, maxDepth, seed,
                                               rows_p, n_rows, rgb_dev))
         self._last_shape = (n_rows, width)
 
     def readImage(self, want_accum=False):
-        """(rgb uint8 [n_rows, w, 3], accum uint64 | None) of the last renderPass on this context."""
+        """(rgb uint8 [n_rows, w, 3], accum uint64 | None) of the last render enqueued on this context
+        whose image stayed in it (renderRows, renderAsync / renderPass without rgb_dev)."""
+        if self._last_shape is None:
+            raise RuntimeError("readImage: nothing has been rendered through this Renderer")
         n_rows, width = self._last_shape
         rgb = np.empty((n_rows, width, 3), np.uint8)
         acc = np.empty((n_rows, width, 3), np.uint64) if want_accum else None
-        _lib.check(self._lib.rtow_read_image(self._h, rgb.ctypes.data if rgb.size else None,
+        self._check(self._lib.rtow_read_image(self._h, rgb.ctypes.data if rgb.size else None,
                                              acc.ctypes.data if acc is not None and acc.size else None))
         return rgb, acc
 
     def sync(self):
-        _lib.check(self._lib.rtow_sync(self._h))
+        self._check(self._lib.rtow_sync(self._h))
 
     def ppm(self, binary=False):
         """The PPM file of the last render as bytes: P3 text exactly as the reference prints it
         (raytracer.nim:28,35), composed on the device; binary=True gives P6."""
         n = C.c_uint64(0)
-        _lib.check(self._lib.rtow_format_ppm(self._h, int(binary), None, 0, C.byref(n)))
+        self._check(self._lib.rtow_format_ppm(self._h, int(binary), None, 0, C.byref(n)))
         buf = np.empty(n.value, np.uint8)
-        _lib.check(self._lib.rtow_format_ppm(self._h, int(binary), buf.ctypes.data, n.value, C.byref(n)))
+        self._check(self._lib.rtow_format_ppm(self._h, int(binary), buf.ctypes.data, n.value, C.byref(n)))
         return buf.tobytes()
 
     def stats(self):
         s = _lib.Stats()
-        _lib.check(self._lib.rtow_get_stats(self._h, C.byref(s)))
+        self._check(self._lib.rtow_get_stats(self._h, C.byref(s)))
         return {"ray_segments": s.ray_segments, "paths": s.paths, "trace_ms": s.trace_ms,
                 "total_ms": s.total_ms, "n_spheres": s.n_spheres, "n_big": s.n_big}
 
     def stream(self):
         p = C.c_void_p()
-        _lib.check(self._lib.rtow_get_stream(self._h, C.byref(p)))
+        self._check(self._lib.rtow_get_stream(self._h, C.byref(p)))
         return p.value
 
 
