@@ -122,6 +122,24 @@ int rtow_sync(rtow_ctx* ctx);
 int rtow_render_pass(rtow_ctx* ctx, int w, int h, int first_sample, int n_samples, int max_depth,
                      uint64_t seed, const int32_t* rows, int n_rows, void* rgb_dev);
 
+/* rtow_render_async for callers that may not allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc between set-up and tear-down.  It has no counterpart in
+ * the reference (which has no device memory to manage).  The radiance sums and the work counters
+ * live in a fixed array inside the library's code object instead of buffers from hipMalloc, and the
+ * call makes no hipMalloc / hipFree or other allocating call; scene and camera must have been
+ * uploaded before (rtow_set_scene allocates).  Differences from rtow_render_async:
+ *   - rows_dev is a DEVICE pointer to n_rows row indices in [0, h) (or NULL with n_rows == h); the
+ *     values are the caller's responsibility, the library cannot inspect them without a copy;
+ *   - rgb_dev (device, n_rows*w*3 bytes) must not be NULL;
+ *   - n_rows * w may not exceed 1 048 576 pixels (RTOW_ERR_INVALID beyond; 1200 x 800 fits);
+ *   - the image cannot be continued by rtow_render_pass or fetched with rtow_read_image /
+ *     rtow_format_ppm: nothing of it stays in the context.
+ * The array (25 MB) exists once per GPU and is shared by every context on that GPU: two such
+ * renders that overlap in time on one GPU race on it and both images are garbage - order them
+ * (one stream, or events).  The pixels equal rtow_render_async's bit for bit. */
+int rtow_render_noalloc(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uint64_t seed,
+                        const int32_t* rows_dev, int n_rows, void* rgb_dev);
+
 /* Copy the image of the most recent render out of the context (waits for it): rgb_out n_rows*w*3
  * bytes, accum_out n_rows*w*3 uint64 fixed-point sums; either may be NULL. */
 int rtow_read_image(rtow_ctx* ctx, uint8_t* rgb_out, uint64_t* accum_out);

@@ -5,6 +5,7 @@
 #include "rtow_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -50,6 +51,23 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Work memory of rtow_render_noalloc: a fixed array inside the code object instead of buffers from
+// hipMalloc.  Every GPU the library runs on holds its own copy (25 MB) until the process ends, and
+// all contexts on one GPU share it.  Layout: 256 bytes of counters (segment count, next path), then
+// three 64-bit radiance sums per pixel.
+constexpr uint32_t kNoAllocMaxPixels = 1u << 20;   // 1 048 576: a 1200 x 800 frame fits
+constexpr size_t kScratchHeader = 256;
+constexpr size_t kScratchBytes = kScratchHeader + sizeof(unsigned long long) * 3 * (size_t)kNoAllocMaxPixels;
+constexpr int kMaxDevices = 64;
+
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+// Device address of `scratch` on each GPU (the array's name is only a host-side handle): looked up
+// once per device by rtow_create with that device current.  The same value whichever thread stores it.
+std::atomic<unsigned char*> g_scratch_ptr[kMaxDevices];
 }  // namespace
 
 struct rtow_ctx {
@@ -72,6 +90,7 @@ struct rtow_ctx {
   bool image_in_workspace = false;            // the last render left its 8-bit image in `rgb`
   bool sums_in_workspace = false;             // ... and its radiance sums in `accum`
   DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
+  unsigned char* scratch_dev = nullptr;       // this GPU's copy of the no-allocation work memory
   uint64_t* host_counters = nullptr;          // pinned, 16 bytes
   char* staging[2] = {nullptr, nullptr};      // pinned, kStagingBytes each: large device-to-host copies go through them
   hipEvent_t staging_ev[2] = {nullptr, nullptr};
@@ -143,6 +162,14 @@ int rtow_create(int device, rtow_ctx** out) {
   for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->host_counters, 16, hipHostMallocDefault);
   if (e == hipSuccess) e = c->counters.reserve(16);
+  if (e == hipSuccess && device < kMaxDevices) {
+    unsigned char* p = g_scratch_ptr[device].load(std::memory_order_acquire);
+    if (!p) {
+      e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));   // `device` is current (hipSetDevice above)
+      if (e == hipSuccess) g_scratch_ptr[device].store(p, std::memory_order_release);
+    }
+    c->scratch_dev = p;
+  }
   if (e != hipSuccess) {
     rtow_destroy(c);
     return fail(RTOW_ERR_DEVICE, "rtow_create: %s", hipGetErrorString(e));
@@ -448,6 +475,38 @@ int rtow_render_async(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_
 int rtow_render_pass(rtow_ctx* c, int w, int h, int first_sample, int n_samples, int max_depth, uint64_t seed,
                      const int32_t* rows, int n_rows, void* rgb_dev) {
   return enqueue_render(c, w, h, n_samples, max_depth, seed, rows, n_rows, rgb_dev, false, first_sample);
+}
+
+int rtow_render_noalloc(rtow_ctx* c, int w, int h, int spp, int max_depth, uint64_t seed, const int32_t* rows_dev,
+                        int n_rows, void* rgb_dev) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_render_noalloc: ctx is NULL");
+  if (!c->have_scene || !c->have_camera)
+    return fail(RTOW_ERR_STATE, "render: call rtow_set_scene and rtow_set_camera first");
+  if (!c->scratch_dev) return fail(RTOW_ERR_STATE, "rtow_render_noalloc: no work memory on device %d", c->device);
+  if (!rgb_dev) return fail(RTOW_ERR_INVALID, "rtow_render_noalloc: rgb_dev is NULL (the image has nowhere to go)");
+  if (w < 2 || h < 2) return fail(RTOW_ERR_INVALID, "render: image %dx%d (width and height must be >= 2)", w, h);
+  if (spp < 1 || max_depth < 1) return fail(RTOW_ERR_INVALID, "render: spp = %d, max_depth = %d", spp, max_depth);
+  if (n_rows < 0 || n_rows > h) return fail(RTOW_ERR_INVALID, "render: n_rows = %d of %d", n_rows, h);
+  if (!rows_dev && n_rows != h) return fail(RTOW_ERR_INVALID, "render: rows_dev == NULL needs n_rows == h");
+  const uint64_t n_pixels = (uint64_t)n_rows * (uint64_t)w;
+  if (n_pixels > kNoAllocMaxPixels)
+    return fail(RTOW_ERR_INVALID, "rtow_render_noalloc: %llu pixels in one call, the fixed work memory holds %u "
+                                  "(use rtow_render_async, or render the frame in row bands)",
+                (unsigned long long)n_pixels, kNoAllocMaxPixels);
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->pending) HIP_TRY(hipStreamSynchronize(c->stream));   // this context's events and counters are still in use
+  FrameTargets t;
+  t.rows_dev = rows_dev;
+  t.counters = c->scratch_dev;
+  t.accum = (unsigned long long*)(c->scratch_dev + kScratchHeader);
+  t.hit_id = nullptr;
+  t.rgb = (uint8_t*)rgb_dev;
+  // the sums live in shared work memory: no later pass may continue this image, and nothing stays in the context
+  c->samples_done = 0;
+  c->last_row_list_valid = false;
+  c->image_in_workspace = false;
+  c->sums_in_workspace = false;
+  return launch_frame(c, w, h, spp, max_depth, seed, 0, n_rows, t);
 }
 
 int rtow_read_image(rtow_ctx* c, uint8_t* rgb_out, uint64_t* accum_out) {

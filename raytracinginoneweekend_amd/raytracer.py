@@ -102,6 +102,14 @@ class Renderer:
                                                rows_p, n_rows, rgb_dev))
         self._last_shape = (n_rows, width)
 
+    def renderNoAlloc(self, width, height, samplesPerPixel, maxDepth, rgb_dev, seed=RENDER_SEED, rows_dev=None,
+                      n_rows=None):
+        """Enqueue a render that allocates nothing (rtow_render_noalloc): rgb_dev and rows_dev are
+        device addresses; at most 1 048 576 pixels; the sums live in per-GPU memory shared by all
+        contexts on that GPU, so such renders must not overlap on one GPU."""
+        self._check(self._lib.rtow_render_noalloc(self._h, width, height, samplesPerPixel, maxDepth, seed, rows_dev,
+                                                  height if n_rows is None else n_rows, rgb_dev))
+
     def renderPass(self, width, height, firstSample, nSamples, maxDepth, seed=RENDER_SEED, rows=None, rgb_dev=None):
         """Progressive refinement: add samples firstSample .. firstSample+nSamples-1 of every pixel to the
         image this context holds (firstSample = 0 starts one).  Asynchronous."""
