@@ -14,8 +14,18 @@
  *     leaves a message for rtow_last_error() (thread local);
  *   - the caller owns every host buffer; the library owns device state inside rtow_ctx;
  *   - one rtow_ctx per host thread and per GPU; a context is not thread safe;
- *   - all arithmetic on the device is binary32 except the intersection of spheres with
- *     |radius| >= 100, which runs in binary64, and the final gamma/quantise step;
+ *   - the PRIMARY segment of every path - the camera ray (raytracer.nim:41-43, camera.nim:34-39), its
+ *     closest hit (hittables.nim:79-88 over hitrecord.nim:55-71) and the sky colour of a miss
+ *     (raytracer.nim:18-20) - is evaluated in binary64 with the reference's operations in the
+ *     reference's order, from the binary64 scene and camera: primary hit ids, and the pixels of a
+ *     one-sample depth-one render, are those of the reference arithmetic.  From the first hit point
+ *     (rounded to binary32) on, all arithmetic is binary32, except the intersection of spheres with
+ *     |radius| >= 100, which keeps a binary64 discriminant, and the final gamma/quantise step;
+ *   - deviations from the reference in the binary32 segments, both to keep rounding noise out of the
+ *     image: a ray scattered on sphere j can meet j again only at its far root (the reference would
+ *     accept any root >= t_min, including a near root that rounding has pushed above it), and one
+ *     sample's channel radiance is clamped to [0, 3.5] before it is summed in 30-bit fixed point (never
+ *     reached while albedos are <= 1, which rtow_set_scene enforces);
  *   - randomness: draw k of path (pixel, sample) is a pure function of (seed, pixel, sample, k),
  *     pixel = y*w + x with y = 0 the top image row.  It replaces the reference's single global
  *     std/random stream (raytracer.nim:41-42,135; basetypes.nim:112,132; hitrecord.nim:119),
@@ -53,6 +63,18 @@ typedef struct {
   float lens_radius;
 } rtow_camera;
 
+/* The same fields in binary64, exactly as initCamera computes them.  Primary rays are generated and
+ * intersected in binary64 (see the conventions above), so a host that has the binary64 camera - the
+ * reference does - should pass it unrounded. */
+typedef struct {
+  double origin[3];
+  double lower_left[3];
+  double horizontal[3];
+  double vertical[3];
+  double u[3], v[3], w[3];
+  double lens_radius;
+} rtow_camera_f64;
+
 /* statistics of the most recent render on a context */
 typedef struct {
   uint64_t ray_segments;  /* world.hit queries (raytracer.nim:11): the numerator of Mrays/s */
@@ -88,8 +110,20 @@ int rtow_set_scene(rtow_ctx* ctx, int n, const float* center_x, const float* cen
                    const float* center_z, const float* radius, const uint8_t* kind,
                    const float* albedo_rgb, const float* fuzz, const float* ir);
 
-/* Upload the camera (camera.nim:4-10). */
+/* The same list from binary64 arrays (Sphere.center, Sphere.radius, Color, fuzz and ir are all Nim
+ * `float` = binary64 in the reference, basetypes.nim:8).  Primary rays are tested against these
+ * values as given; later segments use their binary32 roundings.  rtow_set_scene is this call on
+ * values that are already binary32.  Both refuse (RTOW_ERR_INVALID) a radius that is zero or not
+ * finite in binary32, a centre that is not finite, an unknown kind, and an albedo component outside
+ * [0, 1] on a Lambertian or Metal sphere (the reference accepts those; the fixed-point radiance
+ * sums here could not represent the result faithfully). */
+int rtow_set_scene_f64(rtow_ctx* ctx, int n, const double* center_x, const double* center_y,
+                       const double* center_z, const double* radius, const uint8_t* kind,
+                       const double* albedo_rgb, const double* fuzz, const double* ir);
+
+/* Upload the camera (camera.nim:4-10): binary32 fields (widened exactly) or the binary64 ones. */
 int rtow_set_camera(rtow_ctx* ctx, const rtow_camera* cam);
+int rtow_set_camera_f64(rtow_ctx* ctx, const rtow_camera_f64* cam);
 
 /* render (raytracer.nim:30-46) for the image rows listed in rows[0..n_rows): row 0 is the top
  * row, the first one the reference writes.  rows == NULL means rows 0..h-1 (then n_rows must be

@@ -27,6 +27,16 @@
  *     analytic far root t = -2 (oc.u): the near root is 0 by construction and is dropped, which
  *     removes the binary32 self-intersections that t_min = 0.001|d| cannot catch when the
  *     scattered direction is short;
+ *   - the PRIMARY segment of every path (camera ray, its closest hit, the sky colour of a miss) is
+ *     evaluated with the reference's own binary64 operations in the reference's order
+ *     (raytracer.nim:41-43, camera.nim:34-39, hitrecord.nim:55-71, hittables.nim:79-88,
+ *     raytracer.nim:18-20), on the binary64 scene and camera, so that primary hit ids and the
+ *     pixels of a one-sample depth-one image equal the reference arithmetic's.  The binary32 screen
+ *     above still runs first, on the binary32 roundings of that ray and of the sphere table; only
+ *     spheres that pass it (and the |radius| >= 100 ones) get the binary64 Sphere.hit.  The hit
+ *     point p = orig + t*dir is rounded to binary32 and the path continues in binary32 from there
+ *     (normal, scatter, throughput as for every later segment, with the binary32 unit direction
+ *     of the rounded primary direction);
  *   - a uniform draw is (u32 >> 8) * 2^-24, so rand(-1.0..1.0) = 2*xi - 1 is exact;
  *   - per-sample radiance is accumulated per channel as a 64-bit integer with 30 fractional
  *     bits (order independent), and the writeColor step (raytracer.nim:22-28) runs in binary64
@@ -44,7 +54,8 @@ typedef struct { float x, y, z; } f3;
 static inline float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 
 typedef struct {
-  float cx, cy, cz, r;  /* binary32 roundings of the scene description */
+  double cx64, cy64, cz64, r64; /* the scene description as given (primary segment) */
+  float cx, cy, cz, r;  /* its binary32 roundings (every later segment, and the screen) */
   float r2;             /* r*r */
   float k;              /* |c|^2 - r^2, evaluated in binary64 and rounded once (filter operand) */
   float inv_r;          /* 1/r */
@@ -57,6 +68,7 @@ typedef struct {
 typedef struct {
   f3 origin, llc, hor, ver, u, v;
   float lens_radius;
+  const orc_camera* c64; /* the camera as given (primary rays are generated in binary64) */
 } cam32;
 
 #define BIG_RADIUS 100.0f
@@ -68,6 +80,7 @@ static void prep_scene(const orc_sphere* in, int n, sph32* out, float* cmax) {
   *cmax = 0.0f;
   for (int j = 0; j < n; ++j) {
     sph32 s;
+    s.cx64 = in[j].center[0]; s.cy64 = in[j].center[1]; s.cz64 = in[j].center[2]; s.r64 = in[j].radius;
     s.cx = (float)in[j].center[0]; s.cy = (float)in[j].center[1]; s.cz = (float)in[j].center[2];
     s.r = (float)in[j].radius;
     s.big = fabsf(s.r) >= BIG_RADIUS;
@@ -96,6 +109,7 @@ static void prep_camera(const orc_camera* c, cam32* o) {
   o->origin = cvt3(c->origin); o->llc = cvt3(c->lower_left); o->hor = cvt3(c->horizontal);
   o->ver = cvt3(c->vertical); o->u = cvt3(c->u); o->v = cvt3(c->v);
   o->lens_radius = (float)c->lens_radius;
+  o->c64 = c;
 }
 
 typedef struct { uint32_t key[2]; uint32_t k; } stream;
@@ -213,6 +227,55 @@ static int closest_hit(const sph32* w, int n, float cmax, f3 o, f3 u, float tmin
   return id;
 }
 
+/* Primary segment: HittablesList.hit (hittables.nim:79-88) over Sphere.hit (hitrecord.nim:55-71) in
+ * binary64, in list order with the shrinking t_max, for the spheres the binary32 screen lets through
+ * (o, u: binary32 roundings of the ray, u normalised in binary32) and for the |radius| >= 100 ones. */
+static int primary_hit(const sph32* w, int n, float cmax, const double o64[3], const double d64[3], f3 o, f3 u,
+                       double* t_out) {
+  const double t_min = 0.001; /* raytracer.nim:11 */
+  double closest = INFINITY;
+  int id = -1;
+  const float nou = -dot3(o, u);
+  const float ox2 = 2.0f * o.x, oy2 = 2.0f * o.y, oz2 = 2.0f * o.z;
+  const float oo = dot3(o, o);
+  const float margin_abs = FILTER_MARGIN * (oo + cmax * cmax);
+  const float threshold = oo - margin_abs;
+  const int audit = atomic_load(&g_audit_mode);
+  const double a = d64[0] * d64[0] + d64[1] * d64[1] + d64[2] * d64[2]; /* length_squared, basetypes.nim:88 */
+  for (int j = 0; j < n; ++j) {
+    float fv = 0.0f;
+    if (!w[j].big) {
+      float fn = fmaf(w[j].cx, u.x, nou); fn = fmaf(w[j].cy, u.y, fn); fn = fmaf(w[j].cz, u.z, fn);
+      float ft = fmaf(w[j].cx, ox2, -w[j].k); ft = fmaf(w[j].cy, oy2, ft); ft = fmaf(w[j].cz, oz2, ft);
+      fv = fmaf(fn, fn, ft);
+      if (!audit && !(fv >= threshold)) continue;
+    }
+    const double ocx = o64[0] - w[j].cx64, ocy = o64[1] - w[j].cy64, ocz = o64[2] - w[j].cz64;
+    double half_b = 0.0; /* dot accumulates from 0.0 in index order, basetypes.nim:25-27 */
+    half_b += ocx * d64[0]; half_b += ocy * d64[1]; half_b += ocz * d64[2];
+    const double c = (ocx * ocx + ocy * ocy + ocz * ocz) - w[j].r64 * w[j].r64;
+    const double disc = half_b * half_b - a * c;
+    if (disc < 0) continue;
+    if (audit && !w[j].big) audit_note(fv, threshold, margin_abs);
+    const double sqrtd = sqrt(disc);
+    double root = (-half_b - sqrtd) / a;
+    if (root < t_min || closest < root) {
+      root = (-half_b + sqrtd) / a;
+      if (root < t_min || closest < root) continue;
+    }
+    closest = root;
+    id = j;
+  }
+  *t_out = closest;
+  return id;
+}
+
+/* one channel of a binary64 sample -> fixed point, 30 fractional bits, truncated */
+static inline uint64_t to_fix64(double c) {
+  c = c < 0.0 ? 0.0 : (c > (double)RADIANCE_CLAMP ? (double)RADIANCE_CLAMP : c);
+  return (uint64_t)(uint32_t)(c * 1073741824.0);
+}
+
 typedef struct {
   const sph32* w; int n; float cmax; const cam32* cam;
   int W, H, spp, max_depth; uint64_t seed;
@@ -232,47 +295,67 @@ static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t s
   stream g;
   orc_path_key(jb->seed, pixel, sample, g.key);
   g.k = 0;
-  /* raytracer.nim:41-42 (u before v) */
-  const float xi1 = draw(&g), xi2 = draw(&g);
-  const float su = ((float)i + xi1) / (float)(jb->W - 1);
-  const float sv = ((float)j + xi2) / (float)(jb->H - 1);
-  /* camera.nim:34-39 with basetypes.nim:130-134 */
-  float lx, ly;
-  do { lx = draw_pm1(&g); ly = draw_pm1(&g); } while (fmaf(ly, ly, lx * lx) >= 1.0f);
-  const float rdx = cam->lens_radius * lx, rdy = cam->lens_radius * ly;
-  f3 off, o, d;
-  off.x = fmaf(cam->v.x, rdy, cam->u.x * rdx);
-  off.y = fmaf(cam->v.y, rdy, cam->u.y * rdx);
-  off.z = fmaf(cam->v.z, rdy, cam->u.z * rdx);
-  o.x = cam->origin.x + off.x; o.y = cam->origin.y + off.y; o.z = cam->origin.z + off.z;
-  d.x = fmaf(sv, cam->ver.x, fmaf(su, cam->hor.x, cam->llc.x)) - cam->origin.x - off.x;
-  d.y = fmaf(sv, cam->ver.y, fmaf(su, cam->hor.y, cam->llc.y)) - cam->origin.y - off.y;
-  d.z = fmaf(sv, cam->ver.z, fmaf(su, cam->hor.z, cam->llc.z)) - cam->origin.z - off.z;
+  /* ---- primary segment in binary64: raytracer.nim:41-42 (u before v), camera.nim:34-39 with
+   * basetypes.nim:130-134; every draw is a 24-bit value, exactly representable in both widths */
+  const orc_camera* c64 = cam->c64;
+  const double xi1 = (double)draw(&g), xi2 = (double)draw(&g);
+  const double su = ((double)i + xi1) / (double)(jb->W - 1);
+  const double sv = ((double)j + xi2) / (double)(jb->H - 1);
+  double lx, ly;
+  do { lx = (double)draw(&g) * 2.0 + -1.0; ly = (double)draw(&g) * 2.0 + -1.0; } while (lx * lx + ly * ly >= 1.0);
+  const double rdx = c64->lens_radius * lx, rdy = c64->lens_radius * ly;
+  double o64[3], d64[3];
+  for (int k = 0; k < 3; ++k) {
+    const double off = c64->u[k] * rdx + c64->v[k] * rdy;
+    o64[k] = c64->origin[k] + off;
+    d64[k] = c64->lower_left[k] + su * c64->horizontal[k] + sv * c64->vertical[k] - c64->origin[k] - off;
+  }
+  f3 o = {(float)o64[0], (float)o64[1], (float)o64[2]};
+  f3 d = {(float)d64[0], (float)d64[1], (float)d64[2]};
 
   float tr = 1.0f, tg = 1.0f, tb = 1.0f; /* throughput */
   float rr = 0.0f, rg = 0.0f, rb = 0.0f; /* radiance of the path */
   *first_id = -1;
   int prev = -1; /* sphere the ray starts on */
+  fix[0] = fix[1] = fix[2] = 0;
   for (int depth = jb->max_depth; depth > 0; --depth) { /* depth <= 0 -> black (raytracer.nim:8-9) */
     ++*segments;
     const float len = sqrtf(dot3(d, d));
     const float il = 1.0f / len;
     const f3 u = {d.x * il, d.y * il, d.z * il};
     const float tmin = 0.001f * len;
-    float t;
-    const int id = closest_hit(jb->w, jb->n, jb->cmax, o, u, tmin, prev, &t);
-    if (depth == jb->max_depth) *first_id = id;
-    if (trail) { if (*trail_len < trail_cap) trail[*trail_len] = id; ++*trail_len; }
-    if (id < 0) { /* sky, raytracer.nim:18-20 */
-      const float ts = 0.5f * (u.y + 1.0f);
-      const float a = 1.0f - ts;
-      rr = tr * fmaf(ts, 0.5f, a);
-      rg = tg * fmaf(ts, 0.7f, a);
-      rb = tb * fmaf(ts, 1.0f, a);
-      break;
+    float t = 0.0f;
+    int id;
+    f3 p;
+    if (depth == jb->max_depth) {
+      double t64;
+      id = primary_hit(jb->w, jb->n, jb->cmax, o64, d64, o, u, &t64);
+      *first_id = id;
+      if (trail) { if (*trail_len < trail_cap) trail[*trail_len] = id; ++*trail_len; }
+      if (id < 0) { /* sky, raytracer.nim:18-20, in binary64; the throughput is 1 */
+        const double a = d64[0] * d64[0] + d64[1] * d64[1] + d64[2] * d64[2];
+        const double uy = d64[1] / sqrt(a);
+        const double ts = 0.5 * (uy + 1.0);
+        fix[0] = to_fix64((1.0 - ts) * 1.0 + ts * 0.5);
+        fix[1] = to_fix64((1.0 - ts) * 1.0 + ts * 0.7);
+        fix[2] = to_fix64((1.0 - ts) * 1.0 + ts * 1.0);
+        return;
+      }
+      p.x = (float)(o64[0] + t64 * d64[0]); p.y = (float)(o64[1] + t64 * d64[1]); p.z = (float)(o64[2] + t64 * d64[2]);
+    } else {
+      id = closest_hit(jb->w, jb->n, jb->cmax, o, u, tmin, prev, &t);
+      if (trail) { if (*trail_len < trail_cap) trail[*trail_len] = id; ++*trail_len; }
+      if (id < 0) { /* sky, raytracer.nim:18-20 */
+        const float ts = 0.5f * (u.y + 1.0f);
+        const float a = 1.0f - ts;
+        rr = tr * fmaf(ts, 0.5f, a);
+        rg = tg * fmaf(ts, 0.7f, a);
+        rb = tb * fmaf(ts, 1.0f, a);
+        break;
+      }
+      p.x = fmaf(t, u.x, o.x); p.y = fmaf(t, u.y, o.y); p.z = fmaf(t, u.z, o.z);
     }
     const sph32* s = &jb->w[id];
-    f3 p = {fmaf(t, u.x, o.x), fmaf(t, u.y, o.y), fmaf(t, u.z, o.z)};
     f3 n = {(p.x - s->cx) * s->inv_r, (p.y - s->cy) * s->inv_r, (p.z - s->cz) * s->inv_r};
     const int front = dot3(u, n) < 0.0f;
     if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }

@@ -28,6 +28,14 @@ class CameraStruct(C.Structure):
                 ("lens_radius", C.c_float)]
 
 
+class CameraStruct64(C.Structure):
+    """rtow_camera_f64: the fields as initCamera computes them, unrounded."""
+    _fields_ = [("origin", C.c_double * 3), ("lower_left", C.c_double * 3),
+                ("horizontal", C.c_double * 3), ("vertical", C.c_double * 3),
+                ("u", C.c_double * 3), ("v", C.c_double * 3), ("w", C.c_double * 3),
+                ("lens_radius", C.c_double)]
+
+
 class Stats(C.Structure):
     _fields_ = [("ray_segments", C.c_uint64), ("paths", C.c_uint64), ("trace_ms", C.c_float),
                 ("total_ms", C.c_float), ("n_spheres", C.c_int32), ("n_big", C.c_int32)]
@@ -35,7 +43,7 @@ class Stats(C.Structure):
 
 # every symbol include/rtow.h declares
 SYMBOLS = ["rtow_last_error", "rtow_version", "rtow_device_count", "rtow_create", "rtow_destroy",
-           "rtow_set_scene", "rtow_set_camera", "rtow_render", "rtow_render_async", "rtow_sync",
+           "rtow_set_scene", "rtow_set_scene_f64", "rtow_set_camera", "rtow_set_camera_f64", "rtow_render", "rtow_render_async", "rtow_sync",
            "rtow_render_multi", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
 
 _lib = None
@@ -64,14 +72,32 @@ def _preload_hip_runtime():
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-def load(path):
-    """dlopen one build of the library and declare its prototypes."""
+class _Tolerant:
+    """Prototype declarations for builds that predate some entry points (A/B timing of old builds):
+    attribute writes to symbols the build lacks are dropped."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._cdll, name)
+        except AttributeError:
+            class _Missing:
+                pass
+            return _Missing()
+
+
+def load(path, strict=True):
+    """dlopen one build of the library and declare its prototypes.  strict=False tolerates a build
+    that lacks newer entry points (only for timing old builds against new ones)."""
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `make -C raytracinginoneweekend_amd/csrc` "
             "(or __graft_entry__.build()); this package has no CPU fallback")
     _preload_hip_runtime()
-    L = C.CDLL(path)
+    cdll = C.CDLL(path)
+    L = cdll if strict else _Tolerant(cdll)
     vp = C.c_void_p
     L.rtow_last_error.restype = C.c_char_p
     L.rtow_last_error.argtypes = []
@@ -80,7 +106,9 @@ def load(path):
     L.rtow_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.rtow_destroy.argtypes = [vp]
     L.rtow_set_scene.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rtow_set_scene_f64.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtow_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    L.rtow_set_camera_f64.argtypes = [vp, C.POINTER(CameraStruct64)]
     L.rtow_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp, vp, vp]
     L.rtow_render_async.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp]
     L.rtow_sync.argtypes = [vp]
@@ -93,7 +121,7 @@ def load(path):
     L.rtow_selftest_arithmetic.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rtow_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rtow_get_stream.argtypes = [vp, C.POINTER(vp)]
-    return L
+    return cdll
 
 
 def lib():

@@ -14,9 +14,10 @@ class Camera:
 
     __slots__ = ("origin", "lowerLeftCorner", "horizontal", "vertical", "lensRadius", "u", "v", "w")
 
-    def to_struct(self):
-        """Round the eight fields to binary32 for rtow_set_camera."""
-        s = _lib.CameraStruct()
+    def to_struct(self, binary32=False):
+        """The eight fields for rtow_set_camera_f64 (as computed, binary64), or rounded to binary32
+        for rtow_set_camera."""
+        s = _lib.CameraStruct() if binary32 else _lib.CameraStruct64()
         for name, field in (("origin", self.origin), ("lower_left", self.lowerLeftCorner),
                             ("horizontal", self.horizontal), ("vertical", self.vertical),
                             ("u", self.u), ("v", self.v), ("w", self.w)):

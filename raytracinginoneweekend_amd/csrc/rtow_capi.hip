@@ -80,9 +80,9 @@ struct rtow_ctx {
   // scene
   bool have_scene = false, have_camera = false;
   int n_spheres = 0, n_geom_pad = 0, n_big = 0;
-  DevBuf geom, geom_rr, geom_nk, big, shade;
+  DevBuf geom, geom_rr, geom_nk, geom64, big, shade;
   float cmax = 0.0f;
-  rtow::CameraParams cam;
+  rtow::CameraParams64 cam;
 
   // per-render workspace
   DevBuf ppm_len, ppm_off, ppm_text;          // device-side PPM text of the last image (rtow_format_ppm)
@@ -183,7 +183,7 @@ int rtow_destroy(rtow_ctx* c) {
   if (!c) return RTOW_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
+  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release();
   if (c->host_counters) (void)hipHostFree(c->host_counters);
@@ -197,17 +197,19 @@ int rtow_destroy(rtow_ctx* c) {
   return RTOW_OK;
 }
 
-static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
-                          const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
-                          const float* ir);
+}  // extern "C"
 
-int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
-                   const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
-                   const float* ir) {
-  // the tables are staged in std::vector: an allocation failure must come back as a status, not unwind
-  // through the C boundary
+template <typename T>
+static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T* cz, const T* radius, const uint8_t* kind,
+                          const T* albedo, const T* fuzz, const T* ir);
+
+// the tables are staged in std::vector: an allocation failure must come back as a status, not unwind
+// through the C boundary
+template <typename T>
+static int set_scene_guarded(rtow_ctx* c, int n, const T* cx, const T* cy, const T* cz, const T* radius,
+                             const uint8_t* kind, const T* albedo, const T* fuzz, const T* ir) {
   try {
-    return set_scene_impl(c, n, cx, cy, cz, radius, kind, albedo, fuzz, ir);
+    return set_scene_impl<T>(c, n, cx, cy, cz, radius, kind, albedo, fuzz, ir);
   } catch (const std::bad_alloc&) {
     return fail(RTOW_ERR_NOMEM, "rtow_set_scene: out of host memory staging %d spheres", n);
   } catch (...) {
@@ -215,11 +217,25 @@ int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const f
   }
 }
 
+extern "C" {
+
+int rtow_set_scene(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
+                   const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
+                   const float* ir) {
+  return set_scene_guarded<float>(c, n, cx, cy, cz, radius, kind, albedo, fuzz, ir);
+}
+
+int rtow_set_scene_f64(rtow_ctx* c, int n, const double* cx, const double* cy, const double* cz,
+                       const double* radius, const uint8_t* kind, const double* albedo, const double* fuzz,
+                       const double* ir) {
+  return set_scene_guarded<double>(c, n, cx, cy, cz, radius, kind, albedo, fuzz, ir);
+}
+
 }  // extern "C"
 
-static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, const float* cz,
-                          const float* radius, const uint8_t* kind, const float* albedo, const float* fuzz,
-                          const float* ir) {
+template <typename T>
+static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T* cz, const T* radius, const uint8_t* kind,
+                          const T* albedo, const T* fuzz, const T* ir) {
   if (!c) return fail(RTOW_ERR_INVALID, "rtow_set_scene: ctx is NULL");
   if (n < 0) return fail(RTOW_ERR_INVALID, "rtow_set_scene: n = %d", n);
   if (n > rtow::kMaxSpheres) return fail(RTOW_ERR_INVALID, "rtow_set_scene: n = %d (at most %d spheres)", n, rtow::kMaxSpheres);
@@ -227,8 +243,18 @@ static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, 
     return fail(RTOW_ERR_INVALID, "rtow_set_scene: NULL array with n = %d", n);
   for (int j = 0; j < n; ++j) {
     if (kind[j] > RTOW_DIELECTRIC) return fail(RTOW_ERR_INVALID, "rtow_set_scene: kind[%d] = %d", j, (int)kind[j]);
-    if (!(std::fabs(radius[j]) > 0.0f) || !std::isfinite(radius[j]))
+    const float rf = (float)radius[j];   // the binary32 rounding must be usable too
+    if (!(std::fabs(rf) > 0.0f) || !std::isfinite(rf))
       return fail(RTOW_ERR_INVALID, "rtow_set_scene: radius[%d] = %g", j, (double)radius[j]);
+    if (!std::isfinite((float)cx[j]) || !std::isfinite((float)cy[j]) || !std::isfinite((float)cz[j]))
+      return fail(RTOW_ERR_INVALID, "rtow_set_scene: center[%d] is not finite", j);
+    // Radiance is summed in fixed point with a per-sample ceiling of 3.5 per channel.  With every albedo in
+    // [0, 1] a sample never exceeds the sky's 1.0, so the ceiling is never met; an albedo above 1 (which the
+    // reference would accept) could exceed it and the image would silently differ - refused instead.
+    if (kind[j] != RTOW_DIELECTRIC)
+      for (int k = 0; k < 3; ++k)
+        if (!((float)albedo[3 * j + k] >= 0.0f && (float)albedo[3 * j + k] <= 1.0f))
+          return fail(RTOW_ERR_INVALID, "rtow_set_scene: albedo[%d][%d] = %g is outside [0, 1]", j, k, (double)albedo[3 * j + k]);
   }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));  // a render may still be reading the old tables
@@ -248,28 +274,32 @@ static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, 
   for (int j = 0; j < n_alloc; ++j) geom_at(j, 3) = INFINITY;
   std::vector<float4> exact((size_t)n_alloc, make_float4(0.f, 0.f, 0.f, 0.f));
   std::vector<float> nk((size_t)n_alloc, -INFINITY);
+  // the scene as given, for the binary64 tests of primary rays; every other table holds binary32 roundings
+  std::vector<double4> geom64((size_t)(n > 0 ? n : 1), make_double4(0.0, 0.0, 0.0, 1.0));
   float cmax = 0.0f;
   for (int j = 0; j < n; ++j) {
-    const float r = radius[j];
+    geom64[j] = make_double4((double)cx[j], (double)cy[j], (double)cz[j], (double)radius[j]);
+    const float fx = (float)cx[j], fy = (float)cy[j], fz = (float)cz[j];
+    const float r = (float)radius[j];
     const bool is_big = std::fabs(r) >= rtow::kBigRadius;
-    geom_at(j, 0) = cx[j]; geom_at(j, 1) = cy[j]; geom_at(j, 2) = cz[j];
+    geom_at(j, 0) = fx; geom_at(j, 1) = fy; geom_at(j, 2) = fz;
     if (!is_big) {
-      const double c2 = (double)cx[j] * cx[j] + (double)cy[j] * cy[j] + (double)cz[j] * cz[j];
+      const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
       geom_at(j, 3) = (float)(c2 - (double)r * r);
-      exact[j] = make_float4(cx[j], cy[j], cz[j], r * r);
+      exact[j] = make_float4(fx, fy, fz, r * r);
       nk[j] = -geom_at(j, 3);
       const float reach = (float)std::sqrt(c2) + std::fabs(r);
       if (reach > cmax) cmax = reach;
     }
     if (is_big) {
       rtow::BigSphere b;
-      b.cx = cx[j]; b.cy = cy[j]; b.cz = cz[j]; b.r = r; b.rr = (double)r * (double)r; b.index = j; b.pad_ = 0;
+      b.cx = fx; b.cy = fy; b.cz = fz; b.r = r; b.rr = (double)r * (double)r; b.index = j; b.pad_ = 0;
       big.push_back(b);
     }
     rtow::SphereShade& s = shade[j];
-    s.cx = cx[j]; s.cy = cy[j]; s.cz = cz[j]; s.inv_r = 1.0f / r;
-    s.ar = albedo[3 * j]; s.ag = albedo[3 * j + 1]; s.ab = albedo[3 * j + 2]; s.fuzz = fuzz[j];
-    s.kind = kind[j]; s.ir = ir[j]; s.inv_ir = 1.0f / ir[j]; s.pad_ = 0.f;
+    s.cx = fx; s.cy = fy; s.cz = fz; s.inv_r = 1.0f / r;
+    s.ar = (float)albedo[3 * j]; s.ag = (float)albedo[3 * j + 1]; s.ab = (float)albedo[3 * j + 2]; s.fuzz = (float)fuzz[j];
+    s.kind = kind[j]; s.ir = (float)ir[j]; s.inv_ir = 1.0f / s.ir; s.pad_ = 0.f;
     if (kind[j] == RTOW_DIELECTRIC) {
       // a dielectric has no albedo (hitrecord.nim:109): its slots carry Schlick's r0^2 (hitrecord.nim:103-104)
       // for the two refraction ratios a hit can see, in the binary32 operations the CPU mirror uses per hit
@@ -278,6 +308,8 @@ static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, 
       s.ab = 0.f;
     }
   }
+  HIP_TRY(c->geom64.reserve(sizeof(double4) * geom64.size()));
+  HIP_TRY(hipMemcpy(c->geom64.p, geom64.data(), sizeof(double4) * geom64.size(), hipMemcpyHostToDevice));
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
@@ -304,16 +336,32 @@ static int set_scene_impl(rtow_ctx* c, int n, const float* cx, const float* cy, 
 
 extern "C" {
 
-int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
-  if (!c || !cam) return fail(RTOW_ERR_INVALID, "rtow_set_camera: NULL argument");
-  auto v3 = [](const float* p) { rtow::f3 r = {p[0], p[1], p[2]}; return r; };
-  c->cam.origin = v3(cam->origin); c->cam.llc = v3(cam->lower_left); c->cam.hor = v3(cam->horizontal);
-  c->cam.ver = v3(cam->vertical); c->cam.u = v3(cam->u); c->cam.v = v3(cam->v);
-  c->cam.lens_radius = cam->lens_radius;
+static int set_camera_f64(rtow_ctx* c, const rtow_camera_f64& cam) {
+  for (int k = 0; k < 3; ++k) {
+    c->cam.origin[k] = cam.origin[k]; c->cam.llc[k] = cam.lower_left[k]; c->cam.hor[k] = cam.horizontal[k];
+    c->cam.ver[k] = cam.vertical[k]; c->cam.u[k] = cam.u[k]; c->cam.v[k] = cam.v[k];
+  }
+  c->cam.lens_radius = cam.lens_radius;
   c->have_camera = true;
-  c->samples_done = 0;              // likewise for the previous camera
+  c->samples_done = 0;              // accumulated samples belong to the previous camera: no pass may continue them
   c->last_row_list_valid = false;
   return RTOW_OK;
+}
+
+int rtow_set_camera_f64(rtow_ctx* c, const rtow_camera_f64* cam) {
+  if (!c || !cam) return fail(RTOW_ERR_INVALID, "rtow_set_camera_f64: NULL argument");
+  return set_camera_f64(c, *cam);
+}
+
+int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
+  if (!c || !cam) return fail(RTOW_ERR_INVALID, "rtow_set_camera: NULL argument");
+  rtow_camera_f64 w;   // binary32 widens exactly
+  for (int k = 0; k < 3; ++k) {
+    w.origin[k] = cam->origin[k]; w.lower_left[k] = cam->lower_left[k]; w.horizontal[k] = cam->horizontal[k];
+    w.vertical[k] = cam->vertical[k]; w.u[k] = cam->u[k]; w.v[k] = cam->v[k]; w.w[k] = cam->w[k];
+  }
+  w.lens_radius = cam->lens_radius;
+  return set_camera_f64(c, w);
 }
 
 // where one frame's kernels read their row list and keep their sums, counters and pixels
@@ -333,6 +381,7 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   rtow::TraceParams p;
   p.cam = c->cam;
   p.geom = (const float*)c->geom.p; p.geom_exact = (const float4*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
+  p.geom64 = (const double4*)c->geom64.p; p.n_list = c->n_spheres;
   p.cmax = c->cmax;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;

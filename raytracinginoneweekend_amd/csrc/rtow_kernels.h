@@ -8,17 +8,19 @@ namespace rtow {
 constexpr int kTraceThreads = 256;   // 4 wavefronts per workgroup
 constexpr int kGeomPad = 8;
 constexpr int kMaxSpheres = (1 << 26) - 16;   // list indices travel in 26 bits beside a 6-bit lane number
-constexpr int kCandWords = 640;      // per wave: list of filter survivors awaiting the exact test (512) + closest-hit keys (64 x 8 bytes)
-constexpr int kPoolFields = 9;       // per-wave pool of 64 generated camera rays: o, d, stream, pixel word
+constexpr int kPoolFields = 14;      // per-wave pool, dwords per lane: 64 scattered paths (o, d, throughput, stream, pixel, sphere)
+                                     // or, during a primary scan, the 64 camera rays in binary64 (o, d, |d|^2)
 constexpr int kMaxSpheresExactInLds = 512; // up to this many entries the exact-test records sit in LDS too (8 KB)
 constexpr int kMaxSpheresKInLds = 4096;  // up to this many table entries the filter reads -k from LDS (16 KB)          // the regular sphere table is padded to a multiple of this
 
 struct TraceParams {
-  CameraParams cam;
+  CameraParams64 cam;        // must stay first: the kernel reads it straight from its argument segment
   const float* geom;         // n_geom_pad/4 groups of 16 floats (layout: scan_regular), list order
   const float* geom_nk;      // -k per list entry (n_geom_pad + 4 values): copied to LDS by each workgroup
   const float4* geom_exact;  // (cx, cy, cz, r^2) per list entry, fetched per lane for the exact test
+  const double4* geom64;     // (cx, cy, cz, r) per list entry in binary64: the exact test of primary rays
   int n_geom_pad;
+  int n_list;                // spheres in the list (= entries of geom64 and shade)
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin
   const BigSphere* big;      // spheres intersected in binary64
   int n_big;

@@ -55,6 +55,20 @@ __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_wave_times[12 * 16384];
 #endif
 
+#ifdef RTOW_GUARD
+// debug build: every index into global memory is checked; a violation is recorded (site, value, limit)
+// and the access skipped, so a wrong index shows up as a report instead of a GPU fault
+__device__ unsigned long long g_guard[4 * 16];
+static __device__ __forceinline__ bool guard_ok(int site, long long v, long long limit) {
+  if (v >= 0 && v < limit) return true;
+  if (atomicAdd(&g_guard[4 * site], 1ull) == 0ull) { g_guard[4 * site + 1] = (unsigned long long)v; g_guard[4 * site + 2] = (unsigned long long)limit; }
+  return false;
+}
+#define RTOW_GUARDED(site, v, limit) guard_ok(site, (long long)(v), (long long)(limit))
+#else
+#define RTOW_GUARDED(site, v, limit) true
+#endif
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f8v __attribute__((ext_vector_type(8)));
@@ -120,22 +134,56 @@ static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, co
 // the longest of them (3.9 on average), the shared list takes total / 64 (1.5 on average).
 // The closest-hit rule (smaller t, then larger index) does not depend on the order of the offers.
 typedef unsigned long long __attribute__((address_space(3)))* lds_u64_ptr;
+typedef uint32_t __attribute__((address_space(3)))* lds_u32_ptr;
+typedef const double __attribute__((address_space(3)))* lds_f64_ptr;
 constexpr uint32_t kListEntries = 512;   // per wave; drained when fewer than 256 (one group, all lanes) are free
-constexpr uint32_t kOwnerShift = 26;     // entry = lane << 26 | list index
-static_assert(kCandWords == (int)kListEntries + 128, "per-wave list + 64 keys");
-static_assert(kMaxSpheres + 16 <= (1 << kOwnerShift), "list index must fit beside the lane number");
 
+// An entry of the survivor list is (owner lane, list index).  Tables small enough to sit in LDS
+// entirely (<= kMaxSpheresExactInLds entries) use 16-bit entries - the list then takes 1 KB per wave
+// instead of 2 KB, which is what lets five workgroups per CU keep their tables in LDS.
+template <bool SHORT> struct ListEntry;
+template <> struct ListEntry<true> { typedef uint16_t type; static constexpr uint32_t kShift = 10; };
+template <> struct ListEntry<false> { typedef uint32_t type; static constexpr uint32_t kShift = 26; };
+static_assert(kMaxSpheresExactInLds + 16 <= (1 << ListEntry<true>::kShift), "list index must fit beside the lane number");
+static_assert(kMaxSpheres + 16 <= (1 << ListEntry<false>::kShift), "list index must fit beside the lane number");
+
+// per-wave LDS, in dwords: survivor list, 64 closest-hit keys (8 bytes), 64 closest-hit indices (primary
+// segments), the path pool, the cache of pixel sums
+template <bool SHORT> struct WaveLds {
+  static constexpr uint32_t kList = SHORT ? kListEntries / 2 : kListEntries;
+  static constexpr uint32_t kKeys = kList;            // 128 dwords
+  static constexpr uint32_t kIds = kKeys + 128;       // 64 dwords
+  static constexpr uint32_t kPool = kIds + 64;        // kPoolFields * 64 dwords, 8-byte aligned
+  static constexpr uint32_t kSums = kPool + kPoolFields * 64;
+  static constexpr uint32_t kTotal = kSums + 32;
+  static_assert(kPool % 2 == 0 && kKeys % 2 == 0 && kSums % 2 == 0, "64-bit words must be aligned");
+};
+
+// What the exact tests of a PRIMARY scan need: the binary64 camera rays of the wave (LDS, six
+// doubles per lane, field-major: ox oy oz dx dy dz), the binary64 sphere table, and the list
+// index of every lane's closest hit so far (+1; 0 = none) beside its 64-bit key (the bits of t).
+struct PrimaryCtx {
+  lds_f64_ptr rays;
+  const double4* geom64;
+  lds_u32_ptr best_id;
+  int n_list;   // entries of geom64 (debug builds check indices against it)
+};
+
+template <bool SHORT>
 struct CandList {
-  uint32_t* list;     // LDS: kListEntries words of this wave
-  lds_u64_ptr best;   // LDS: 64 words of this wave, lane L's closest hit so far (hit_key)
+  typedef typename ListEntry<SHORT>::type entry_t;
+  entry_t* list;      // LDS: kListEntries entries of this wave
+  lds_u64_ptr best;   // LDS: 64 words of this wave, lane L's closest hit so far (hit_key, or the bits of a binary64 t)
   uint32_t n;         // wave-uniform: entries in the list
   uint32_t lane;
 };
 
 // smaller t first, then the larger list index; id = -1 (nothing hit) loses every tie
+// (unsigned arithmetic: id = -1 maps to 0x80000000, which signed subtraction may not produce)
 static __device__ __forceinline__ unsigned long long hit_key(float t, int id) {
-  return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(uint32_t)(0x7fffffff - id);
+  return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)id);
 }
+static __device__ __forceinline__ int hit_key_id(unsigned long long key) { return (int)(0x7fffffffu - (uint32_t)key); }
 
 static __device__ __forceinline__ void lds_order() {
   // one wave's LDS requests are served in order; the compiler only has to keep them in order too
@@ -145,12 +193,13 @@ static __device__ __forceinline__ void lds_order() {
 }
 
 // wave-uniform control flow; `pass` differs per lane
-static __device__ __forceinline__ void cand_push(CandList& c, bool pass, int j) {
+template <bool SHORT>
+static __device__ __forceinline__ void cand_push(CandList<SHORT>& c, bool pass, int j) {
   // Usually one of a group's four spheres has survivors; the wave-uniform branch skips the other three
   // pushes (instructions issued with an empty execution mask still take their issue slots).
   const uint64_t m = __ballot(pass);
   if (m != 0) {
-    if (pass) c.list[c.n + lanes_below(m)] = (c.lane << kOwnerShift) | (uint32_t)j;
+    if (pass) c.list[c.n + lanes_below(m)] = (typename CandList<SHORT>::entry_t)((c.lane << ListEntry<SHORT>::kShift) | (uint32_t)j);
     c.n += (uint32_t)__popcll(m);
   }
 }
@@ -159,33 +208,80 @@ static __device__ __forceinline__ float from_lane(int byte_index, float v) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_index, __float_as_int(v)));
 }
 
+// Sphere.hit (hitrecord.nim:55-71) for a primary ray, operation for operation in binary64: a = |dir|^2
+// is live, the direction is not normalised, t_min = 0.001 (raytracer.nim:11).  t_max is handled by
+// the caller's minimum (hittables.nim:84-88 shrinks it as it goes, which selects the same root).
+static __device__ __forceinline__ bool sphere_hit_f64(double ox, double oy, double oz, double dx, double dy, double dz,
+                                                      double a, double4 sp, double& root) {
+  const double ocx = ox - sp.x, ocy = oy - sp.y, ocz = oz - sp.z;
+  double half_b = 0.0;   // dot accumulates from 0.0 in index order (basetypes.nim:25-27)
+  half_b += ocx * dx; half_b += ocy * dy; half_b += ocz * dz;
+  const double c = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w * sp.w;
+  const double disc = half_b * half_b - a * c;
+  if (disc < 0) return false;
+  const double sqrtd = sqrt(disc);
+  root = (-half_b - sqrtd) / a;
+  if (root < 0.001) {
+    root = (-half_b + sqrtd) / a;
+    if (root < 0.001) return false;
+  }
+  return true;
+}
+
 // Must run with all 64 lanes active (rays are read from their owners' registers).
-template <typename ExactPtr>
-static __device__ __forceinline__ void cand_drain(CandList& c, ExactPtr exact, f3 o, f3 u, float tmin,
-                                                  int prev RTOW_PROF_PARAM) {
+// PRIMARY: the list belongs to a batch of camera rays - the exact test is the reference's binary64
+// one on the rays in pc.rays, and a lane's closest hit is a 64-bit t plus an index word (smaller t wins,
+// equal t goes to the later list entry, hittables.nim:84-88).
+template <bool PRIMARY, bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void cand_drain(CandList<SHORT>& c, ExactPtr exact, f3 o, f3 u, float tmin,
+                                                  int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
+  constexpr uint32_t kShift = ListEntry<SHORT>::kShift;
   lds_order();
   const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.n);   // a scalar loop bound
   for (uint32_t base = 0; base < n; base += 64u) {
-    RTOW_COUNT(10, 1);
+    RTOW_COUNT(PRIMARY ? 12 : 10, 1);
     const uint32_t k = base + c.lane;
     const bool has = k < n;
-    const uint32_t entry = c.list[k];   // lanes past the end read into the key words behind the list: unused
-    const int owner = (int)((entry >> kOwnerShift) << 2);
-    const int j = (int)(entry & ((1u << kOwnerShift) - 1u));
-    const f3 oo = {from_lane(owner, o.x), from_lane(owner, o.y), from_lane(owner, o.z)};
-    const f3 uu = {from_lane(owner, u.x), from_lane(owner, u.y), from_lane(owner, u.z)};
-    const float tm = from_lane(owner, tmin);
-    const int pv = __builtin_amdgcn_ds_bpermute(owner, prev);
-    if (has) {
-      const f4v sp = exact[j];   // (cx, cy, cz, r^2)
-      const float ocx = oo.x - sp.x, ocy = oo.y - sp.y, ocz = oo.z - sp.z;
-      float b = ocx * uu.x; b = fmaf(ocy, uu.y, b); b = fmaf(ocz, uu.z, b);
-      float m = fmaf(-ocx, ocx, sp.w); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
-      const float disc = fmaf(b, b, m);
-      float t;
-      const bool ok = regular_candidate(b, disc, tm, j == pv, t);
-      if (disc >= 0.0f && ok)
-        __hip_atomic_fetch_min(c.best + (entry >> kOwnerShift), hit_key(t, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint32_t entry = c.list[k];   // lanes past the end read stale entries: unused
+    const uint32_t owner = (entry >> kShift) & 63u;
+    const int j = (int)(entry & ((1u << kShift) - 1u));
+    if (PRIMARY) {
+      bool valid = false;
+      unsigned long long tb = ~0ull;
+      if (has && RTOW_GUARDED(0, j, pc.n_list)) {
+        const lds_f64_ptr r = pc.rays + owner;
+        const double dx = r[192], dy = r[256], dz = r[320];
+        const double a = dx * dx + dy * dy + dz * dz;   // length_squared (basetypes.nim:88)
+        double root;
+        valid = sphere_hit_f64(r[0], r[64], r[128], dx, dy, dz, a, pc.geom64[j], root);
+        tb = (unsigned long long)__double_as_longlong(root);
+      }
+      // t > 0, so the bit patterns order like the values.  A lane that lowers the key voids the index
+      // word of the previous holder; every lane whose t is the key afterwards then offers its index.
+      unsigned long long old = 0;
+      if (valid) old = __hip_atomic_fetch_min(c.best + owner, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      lds_order();
+      const bool winner = valid && c.best[owner] == tb;
+      if (winner && old > tb) pc.best_id[owner] = 0u;
+      lds_order();
+      if (winner) __hip_atomic_fetch_max(pc.best_id + owner, (uint32_t)j + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+      const int ob = (int)(owner << 2);
+      const f3 oo = {from_lane(ob, o.x), from_lane(ob, o.y), from_lane(ob, o.z)};
+      const f3 uu = {from_lane(ob, u.x), from_lane(ob, u.y), from_lane(ob, u.z)};
+      const float tm = from_lane(ob, tmin);
+      const int pv = __builtin_amdgcn_ds_bpermute(ob, prev);
+      if (has) {
+        const f4v sp = exact[j];   // (cx, cy, cz, r^2)
+        const float ocx = oo.x - sp.x, ocy = oo.y - sp.y, ocz = oo.z - sp.z;
+        float b = ocx * uu.x; b = fmaf(ocy, uu.y, b); b = fmaf(ocz, uu.z, b);
+        float m = fmaf(-ocx, ocx, sp.w); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
+        const float disc = fmaf(b, b, m);
+        float t;
+        const bool ok = regular_candidate(b, disc, tm, j == pv, t);
+        if (disc >= 0.0f && ok)
+          __hip_atomic_fetch_min(c.best + owner, hit_key(t, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
   }
   c.n = 0;
@@ -214,10 +310,10 @@ static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v&
   return r;
 }
 
-template <typename ExactPtr>
+template <bool PRIMARY, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v nk, int j, ExactPtr exact,
-                                                  CandList& cand, const ScanRay& r, f3 o, f3 u, float tmin,
-                                                  int prev RTOW_PROF_PARAM) {
+                                                  CandList<SHORT>& cand, const ScanRay& r, f3 o, f3 u, float tmin,
+                                                  int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
   const f2v f0 = pair_filter(grp.a.s01, grp.a.s23, grp.a.s45, nk.xy, r);
   const f2v f1 = pair_filter(grp.a.s67, grp.b.xy, grp.b.zw, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
@@ -228,7 +324,7 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v 
     cand_push(cand, f0.y >= r.threshold, j + 1);
     cand_push(cand, f1.x >= r.threshold, j + 2);
     cand_push(cand, f1.y >= r.threshold, j + 3);
-    if (cand.n > kListEntries - 256u) cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
+    if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
   }
 }
 
@@ -242,15 +338,16 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v 
 // the SGPR copy of k (moved to VGPRs first; same arithmetic, two more instructions per group).
 typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 
-// Called by all 64 lanes of the wave; lanes without a path pass live = false and offer nothing.
-template <bool K_LDS, typename ExactPtr>
+// Called by all 64 lanes of the wave; lanes without a ray pass live = false and offer nothing.  The
+// caller has put every lane's closest hit so far into cand.best (and pc.best_id for a primary scan) and
+// reads the result back from there.
+template <bool PRIMARY, bool K_LDS, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exact, const f4v* nk_lds,
-                                                    CandList& cand, int n_groups, float cmax, bool live, f3 o, f3 u,
-                                                    float tmin, int prev, float& best, int& id RTOW_PROF_PARAM) {
+                                                    CandList<SHORT>& cand, int n_groups, float cmax, bool live, f3 o, f3 u,
+                                                    float tmin, int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
   ScanRay r = scan_ray(o, u, cmax);
   if (!live) r.threshold = INFINITY;
-  cand.best[cand.lane] = hit_key(best, id);   // what the binary64 spheres left; read back after the last drain
   // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
   // immediate offsets.  (Left to itself the compiler keeps the address in an SGPR and copies it to
   // a VGPR for every read: one more VALU instruction per group.)
@@ -262,15 +359,12 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS>(geom, g + 1, kb);
     if (K_LDS) kb = nk[1];
-    group_test(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev RTOW_PROF_ARG);
+    group_test<PRIMARY>(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
     ga = load_group<K_LDS>(geom, g + 2, ka);
     if (K_LDS) { ka = nk[2]; nk += 2; }
-    group_test(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev RTOW_PROF_ARG);
+    group_test<PRIMARY>(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
   }
-  cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
-  const unsigned long long key = cand.best[cand.lane];
-  best = __uint_as_float((uint32_t)(key >> 32));
-  id = 0x7fffffff - (int)(uint32_t)key;
+  cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
 
 // The same closest-hit query for a wave that has only a few paths left (the end of a frame, when no
@@ -283,13 +377,12 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
 // Needs -k and the exact-test records in LDS (tables up to kMaxSpheresExactInLds entries).
 constexpr uint32_t kSparseLanes = 12;
 
-template <typename ExactPtr>
-static __device__ __forceinline__ void scan_sparse(ExactPtr exact, const f4v* nk_lds, CandList& cand, int n_pad,
+template <bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void scan_sparse(ExactPtr exact, const f4v* nk_lds, CandList<SHORT>& cand, int n_pad,
                                                    float cmax, bool live, f3 o, f3 u, float tmin, int prev,
-                                                   float& best, int& id RTOW_PROF_PARAM) {
+                                                   const PrimaryCtx& pc RTOW_PROF_PARAM) {
   typedef const float __attribute__((address_space(3)))* lds_f32_ptr;
   const lds_f32_ptr nk = (lds_f32_ptr)(const float*)nk_lds;
-  cand.best[cand.lane] = hit_key(best, id);
   uint64_t todo = __ballot(live);
   while (todo != 0) {
     const int owner = __builtin_ctzll(todo);
@@ -307,16 +400,13 @@ static __device__ __forceinline__ void scan_sparse(ExactPtr exact, const f4v* nk
       }
       const uint64_t m = __ballot(pass);
       if (m != 0) {
-        if (pass) cand.list[cand.n + lanes_below(m)] = ((uint32_t)owner << kOwnerShift) | (uint32_t)j;
+        if (pass) cand.list[cand.n + lanes_below(m)] = (typename CandList<SHORT>::entry_t)(((uint32_t)owner << ListEntry<SHORT>::kShift) | (uint32_t)j);
         cand.n += (uint32_t)__popcll(m);
-        if (cand.n > kListEntries - 64u) cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
+        if (cand.n > kListEntries - 64u) cand_drain<false>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
       }
     }
   }
-  cand_drain(cand, exact, o, u, tmin, prev RTOW_PROF_ARG);
-  const unsigned long long key = cand.best[cand.lane];
-  best = __uint_as_float((uint32_t)(key >> 32));
-  id = 0x7fffffff - (int)(uint32_t)key;
+  cand_drain<false>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
 
 static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -340,22 +430,21 @@ constexpr uint32_t kNoPixel = 0xffffffffu;
 struct SumCache {
   lds_u64_ptr words;             // this wave's kSumSlots * 3 words
   uint32_t tags;                 // lane s < kSumSlots: the pixel slot s holds (one VGPR; scalar registers are scarce here)
+#ifdef RTOW_GUARD
+  long long n_pixels;
+#endif
 };
 
 static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum, const SumCache& c, uint32_t slot,
                                                        uint32_t pix, uint32_t lane) {
   // LDS serves one wave's requests in order: the adds of earlier instructions are in the words read here
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  lds_order();
   if (lane < 3u) {
     const unsigned long long v = c.words[3u * slot + lane];
     c.words[3u * slot + lane] = 0ull;
-    atomicAdd(&accum[3ull * pix + lane], v);
+    if (RTOW_GUARDED(1, pix, c.n_pixels)) atomicAdd(&accum[3ull * pix + lane], v);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  lds_order();
 }
 
 // Must be called by all 64 lanes together; lanes with `want` set hand over (accpix, acc_*).
@@ -390,37 +479,57 @@ static __device__ __forceinline__ void sum_cache_drain(unsigned long long* accum
   c.tags = kNoPixel;
 }
 
+// fields of a pool entry: a path whose primary segment hit something and scattered
+enum : uint32_t { kPoolO = 0, kPoolD = 3, kPoolT = 6, kPoolX0 = 9, kPoolKey1 = 10, kPoolPix = 11, kPoolPrev = 12 };
+static_assert(kPoolFields >= 14, "the pool region also holds seven doubles per lane during a primary scan");
+
+// The wave alternates between two kinds of iteration, each one sphere scan at (nearly) full lanes:
+//
+//  PRIMARY  when lanes are idle and the pool is empty: the next (up to) 64 paths of the chunk are started
+//           together, one per lane.  Camera rays (raytracer.nim:41-43, camera.nim:34-39) and their closest hit
+//           are evaluated in binary64 exactly as the reference does - the binary32 screen runs on the
+//           rounded ray, the spheres that pass get the binary64 Sphere.hit - a miss adds the binary64 sky
+//           colour to its pixel and ends, a hit is shaded (binary32 from the rounded hit point on) and the
+//           scattered path goes into the per-wave pool in LDS.  Lanes with a path in flight just wait.
+//  BOUNCE   otherwise: idle lanes have taken paths from the pool; every lane with a path traces its next
+//           segment in binary32 (scan, shade, scatter or end).
+//
 // K_LDS: -k per sphere in LDS (tables up to kMaxSpheresKInLds entries).  X_LDS: the records of the
 // exact test (16 bytes per sphere) in LDS as well (tables up to kMaxSpheresExactInLds entries): a
-// round of exact tests then waits for LDS, not for L2.
+// round of exact tests then waits for LDS, not for L2, and the survivor list has 16-bit entries.
 template <bool K_LDS, bool X_LDS>
 __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
-  // LDS: candidate lists + closest-hit keys [4 waves][kCandWords], path pools [4 waves][kPoolFields][64], sum caches
-  // [4 waves][kSumCacheDwords], then
-  // (K_LDS) -k per sphere, then (X_LDS) the exact-test records
+  // LDS: [4 waves][WaveLds::kTotal], then (K_LDS) -k per sphere, then (X_LDS) the exact-test records
   extern __shared__ f4v lds_raw[];
-  uint32_t* const stacks = (uint32_t*)lds_raw;
-  constexpr uint32_t kPerWaveDwords = kCandWords + kPoolFields * 64 + kSumCacheDwords;
-  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * kPerWaveDwords / 4;
+  typedef WaveLds<X_LDS> L;
+  uint32_t* const wave_lds = (uint32_t*)lds_raw + (threadIdx.x >> 6) * L::kTotal;
+  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * L::kTotal / 4;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  uint32_t* const pool = stacks + (kTraceThreads / 64) * kCandWords + wave * (kPoolFields * 64);
+  uint32_t* const pool = wave_lds + L::kPool;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
-  CandList cand;
-  cand.list = stacks + wave * kCandWords;
-  cand.best = (lds_u64_ptr)(unsigned long long*)(cand.list + kListEntries);
+  CandList<X_LDS> cand;
+  cand.list = (typename CandList<X_LDS>::entry_t*)wave_lds;
+  cand.best = (lds_u64_ptr)(unsigned long long*)(wave_lds + L::kKeys);
   cand.n = 0;
   cand.lane = lane;
+  PrimaryCtx pc;
+  pc.rays = (lds_f64_ptr)(const double*)pool;
+  pc.geom64 = P.geom64;
+  pc.n_list = P.n_list;
+  pc.best_id = (lds_u32_ptr)(wave_lds + L::kIds);
   SumCache sums;
   {
-    uint32_t* const mine = stacks + (kTraceThreads / 64) * (kCandWords + kPoolFields * 64) + wave * kSumCacheDwords;
+    uint32_t* const mine = wave_lds + L::kSums;
     if (lane < kSumCacheDwords) mine[lane] = 0u;   // read back only by this wave, in order
     sums.words = (lds_u64_ptr)(unsigned long long*)mine;
     sums.tags = kNoPixel;
+#ifdef RTOW_GUARD
+    sums.n_pixels = (long long)P.n_rows * P.W;
+#endif
   }
   if (K_LDS) {
     const int n4 = P.n_geom_pad / 4 + 1;
-    f4v* const dst = lds_raw + (kTraceThreads / 64) * kPerWaveDwords / 4;
+    f4v* const dst = lds_raw + (kTraceThreads / 64) * L::kTotal / 4;
     for (int i = threadIdx.x; i < n4; i += kTraceThreads) dst[i] = ((const f4v*)P.geom_nk)[i];
     if (X_LDS) {
       f4v* const xdst = dst + n4;
@@ -435,10 +544,11 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   // pixel-major order (all samples of a pixel, then the next pixel of the row list).
   uint32_t e_next = 0, e_end = 0;     // offsets inside the chunk
   unsigned long long seen = 0;        // first path of this wave's previous chunk
-  uint32_t pool_n = 0, pool_head = 0; // camera rays generated into the pool / already handed to lanes
+  uint32_t pool_n = 0, pool_head = 0; // scattered paths in the pool / already handed to lanes
   uint32_t p_base = 0, s_base = 0;    // pixel (index in the row list's image) and sample of the chunk's first path
   uint32_t r_base = 0, i_base = 0;    // row (in the row list) and column of that pixel
   bool exhausted = false;
+  uint32_t nseg_primary = 0;          // primary segments traced by this wave
 
   // per lane: the path in flight
   bool alive = false;
@@ -446,7 +556,6 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   float tr = 0, tg = 0, tb = 0;
   Stream g = {0, 0};
   int depth = 0, prev = -1;
-  bool first_sample = false;
   // per lane: radiance sums of the pixel it is working on
   uint32_t accpix = 0xffffffffu;
   unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
@@ -462,13 +571,37 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 
   for (;;) {
     const unsigned long long t_refill = RTOW_CLOCK();
-    // ---- refill idle lanes
-    for (;;) {
+    // ---- hand pooled paths to the idle lanes
+    {
       const uint64_t need = __ballot(!alive);
-      if (need == 0) break;
-      if (pool_head >= pool_n) {
-       if (e_next >= e_end) {
-        if (exhausted) break;
+      const uint32_t avail = pool_n - pool_head;
+      if (need != 0 && avail != 0) {
+        const uint32_t rank = lanes_below(need);
+        const uint32_t cnt = (uint32_t)__popcll(need);
+        const bool take = !alive && rank < avail;
+        const uint32_t entry = take ? pool_head + rank : 0u;
+        const uint32_t pix_local = pool[kPoolPix * 64 + entry];
+        // a lane that moves on to another pixel hands its sums over first
+        flush_sums(P.accum, sums, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
+        if (take) {
+          if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
+          o.x = __uint_as_float(pool[(kPoolO + 0) * 64 + entry]); o.y = __uint_as_float(pool[(kPoolO + 1) * 64 + entry]);
+          o.z = __uint_as_float(pool[(kPoolO + 2) * 64 + entry]); d.x = __uint_as_float(pool[(kPoolD + 0) * 64 + entry]);
+          d.y = __uint_as_float(pool[(kPoolD + 1) * 64 + entry]); d.z = __uint_as_float(pool[(kPoolD + 2) * 64 + entry]);
+          tr = __uint_as_float(pool[(kPoolT + 0) * 64 + entry]); tg = __uint_as_float(pool[(kPoolT + 1) * 64 + entry]);
+          tb = __uint_as_float(pool[(kPoolT + 2) * 64 + entry]);
+          g.x0 = pool[kPoolX0 * 64 + entry]; g.key1 = pool[kPoolKey1 * 64 + entry];
+          prev = (int)pool[kPoolPrev * 64 + entry];
+          depth = P.max_depth - 1;
+          alive = true;
+        }
+        pool_head += min(cnt, avail);
+      }
+    }
+    // ---- lanes still idle and nothing pooled: start the next paths of the chunk (a PRIMARY iteration)
+    uint32_t n_gen = 0;
+    if (__ballot(!alive) != 0 && pool_head >= pool_n) {
+      if (e_next >= e_end && !exhausted) {
         // guided self-scheduling: a quarter of an even share of what was left when this wave
         // last looked, clamped to [chunk_min, chunk_max] and rounded down to whole wavefronts
         uint32_t want = P.chunk_max;
@@ -494,173 +627,245 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           }
 #endif
           exhausted = true;
-          break;
-        }
-        seen = first;
-        {
-          // The SIMD's arbiter serves its resident waves by priority, then age, and age never
-          // changes for persistent waves: left alone, the oldest wave of a SIMD runs ten times as
-          // many iterations as the youngest, which then sits on stale work when the frame runs out
-          // and keeps the grid alive for milliseconds.  Each wave therefore compares what it has
-          // consumed with an even share of what has been handed out and raises its priority when it
-          // is behind, lowers it when it is ahead.
-          const float ahead = my_paths - (float)first * inv_waves;
-          if (ahead < -512.0f) __builtin_amdgcn_s_setprio(3);
-          else if (ahead < 0.0f) __builtin_amdgcn_s_setprio(2);
-          else if (ahead < 512.0f) __builtin_amdgcn_s_setprio(1);
-          else __builtin_amdgcn_s_setprio(0);
-          my_paths += (float)want;
-        }
-        const unsigned long long left = P.total_paths - first;
-        // Pixels are handed out from the LAST pixel of the row list backwards, so a frame ends on its
-        // top rows.  The waves retire only when their longest path has ended, and in the scenes this
-        // renderer is used on the top of the frame is sky (one segment per path) while the bottom is
-        // ground and spheres (paths of up to max_depth segments): finishing on cheap paths cuts the
-        // time the grid spends draining from milliseconds to one iteration.
-        const uint32_t p_seq = (uint32_t)(first / (uint32_t)P.spp);
-        s_base = (uint32_t)(first - (unsigned long long)p_seq * (uint32_t)P.spp);
-        p_base = (uint32_t)P.n_rows * (uint32_t)P.W - 1u - p_seq;
-        r_base = p_base / (uint32_t)P.W;
-        i_base = p_base - r_base * (uint32_t)P.W;
-        e_next = 0;
-        e_end = left < want ? (uint32_t)left : want;
-       }
-        // ---- generate: the next (up to) 64 paths of the chunk, one per lane, ALL lanes at work
-        // The camera (19 scalars) is read from the kernel arguments here, every time: kept in scalar
-        // registers across the sphere scan it pushes other values out into vector-register lanes.
-        typedef const float __attribute__((address_space(4)))* karg_ptr;
-        karg_ptr cf = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();   // TraceParams starts with cam: 19 floats
-        asm volatile("" : "+s"(cf));
-        static_assert(offsetof(TraceParams, cam) == 0 && sizeof(CameraParams) == 19 * sizeof(float), "camera layout");
-        CameraParams cam;
-        cam.origin = {cf[0], cf[1], cf[2]}; cam.llc = {cf[3], cf[4], cf[5]}; cam.hor = {cf[6], cf[7], cf[8]};
-        cam.ver = {cf[9], cf[10], cf[11]}; cam.u = {cf[12], cf[13], cf[14]}; cam.v = {cf[15], cf[16], cf[17]};
-        cam.lens_radius = cf[18];
-        const uint32_t n_gen = min(64u, e_end - e_next);
-        const bool gen = lane < n_gen;
-        // (pixel, sample) of lane's path: e counts samples from the first sample of the chunk's
-        // first pixel.  With spp >= chunk_max it overflows spp at most once.
-        const uint32_t e = s_base + e_next + (gen ? lane : 0u);
-        uint32_t dp, sample;
-        if ((uint32_t)P.spp >= P.chunk_max) {
-          dp = e >= (uint32_t)P.spp ? 1u : 0u;
-          sample = e - (dp ? (uint32_t)P.spp : 0u);
         } else {
-          // e < 2 * chunk_max + spp and spp < chunk_max here: exact (2^32 / 1 does not fit inv_spp)
-          dp = P.spp == 1 ? e : __umulhi(e, P.inv_spp);
-          sample = e - dp * (uint32_t)P.spp;
+          seen = first;
+          {
+            // The SIMD's arbiter serves its resident waves by priority, then age, and age never
+            // changes for persistent waves: left alone, the oldest wave of a SIMD runs ten times as
+            // many iterations as the youngest, which then sits on stale work when the frame runs out
+            // and keeps the grid alive for milliseconds.  Each wave therefore compares what it has
+            // consumed with an even share of what has been handed out and raises its priority when it
+            // is behind, lowers it when it is ahead.
+            const float ahead = my_paths - (float)first * inv_waves;
+            if (ahead < -512.0f) __builtin_amdgcn_s_setprio(3);
+            else if (ahead < 0.0f) __builtin_amdgcn_s_setprio(2);
+            else if (ahead < 512.0f) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            my_paths += (float)want;
+          }
+          const unsigned long long left = P.total_paths - first;
+          // Pixels are handed out from the LAST pixel of the row list backwards, so a frame ends on its
+          // top rows.  The waves retire only when their longest path has ended, and in the scenes this
+          // renderer is used on the top of the frame is sky (one segment per path) while the bottom is
+          // ground and spheres (paths of up to max_depth segments): finishing on cheap paths cuts the
+          // time the grid spends draining from milliseconds to one iteration.
+          const uint32_t p_seq = (uint32_t)(first / (uint32_t)P.spp);
+          s_base = (uint32_t)(first - (unsigned long long)p_seq * (uint32_t)P.spp);
+          p_base = (uint32_t)P.n_rows * (uint32_t)P.W - 1u - p_seq;
+          r_base = p_base / (uint32_t)P.W;
+          i_base = p_base - r_base * (uint32_t)P.W;
+          e_next = 0;
+          e_end = left < want ? (uint32_t)left : want;
         }
-        if (gen) {
-          uint32_t r = r_base;
-          int ci = (int)i_base - (int)dp;
-          while (ci < 0) { ci += P.W; --r; }
-          const int y = P.rows ? P.rows[r] : (int)r;
-          Stream g2 = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + P.sample_base);
-          f3 o2, d2;
-          camera_ray(cam, ci, P.H - 1 - y, P.W, P.H, g2, o2, d2);
-          pool[0 * 64 + lane] = __float_as_uint(o2.x); pool[1 * 64 + lane] = __float_as_uint(o2.y);
-          pool[2 * 64 + lane] = __float_as_uint(o2.z); pool[3 * 64 + lane] = __float_as_uint(d2.x);
-          pool[4 * 64 + lane] = __float_as_uint(d2.y); pool[5 * 64 + lane] = __float_as_uint(d2.z);
-          pool[6 * 64 + lane] = g2.x0; pool[7 * 64 + lane] = g2.key1;
-          // local pixel index (< 2^31 / 3); top bit: sample 0 of the pixel (it records the hit-id plane)
-          pool[8 * 64 + lane] = (p_base - dp) | ((sample + P.sample_base == 0u) ? 0x80000000u : 0u);
-        }
-        RTOW_COUNT(14, 1);
-        e_next += n_gen;
-        pool_n = n_gen;
-        pool_head = 0;
-        // the pool is written and read by different lanes of this one wave: LDS serves a wave's
-        // requests in order, the compiler only has to keep them in order too
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      // ---- hand pooled paths to the idle lanes
-      const uint32_t avail = pool_n - pool_head;
-      const uint32_t rank = lanes_below(need);
-      const uint32_t cnt = (uint32_t)__popcll(need);
-      const bool take = !alive && rank < avail;
-      const uint32_t entry = take ? pool_head + rank : 0u;
-      const uint32_t pix_word = pool[8 * 64 + entry];
-      const uint32_t pix_local = pix_word & 0x7fffffffu;
-      // a lane that moves on to another pixel hands its sums over first
-      flush_sums(P.accum, sums, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
-      if (take) {
-        if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
-        o.x = __uint_as_float(pool[0 * 64 + entry]); o.y = __uint_as_float(pool[1 * 64 + entry]);
-        o.z = __uint_as_float(pool[2 * 64 + entry]); d.x = __uint_as_float(pool[3 * 64 + entry]);
-        d.y = __uint_as_float(pool[4 * 64 + entry]); d.z = __uint_as_float(pool[5 * 64 + entry]);
-        g.x0 = pool[6 * 64 + entry]; g.key1 = pool[7 * 64 + entry];
-        tr = tg = tb = 1.0f;
-        depth = P.max_depth;
-        prev = -1;
-        first_sample = (pix_word >> 31) != 0u;
-        alive = true;
-      }
-      pool_head += min(cnt, avail);
+      if (e_next < e_end) n_gen = min(64u, e_end - e_next);
     }
-    if (__ballot(alive) == 0) break;
-    RTOW_COUNT(4, __popcll(__ballot(alive)));
+    const bool primary = n_gen != 0;
+    if (!primary && __ballot(alive) == 0) break;
     const unsigned long long t_seg = RTOW_CLOCK();
 
-    // ---- one segment: world.hit + scatter (raytracer.nim:11-16)
-    f3 u = {0, 0, 1};
-    float tmin = 0.0f, best = INFINITY;
-    int id = -1;
-    if (alive) {
-      ++nseg;
-      segment_begin(d, u, tmin);
-      for (int k = 0; k < P.n_big; ++k) {
-        const BigSphere bs = P.big[k];
-        float t;
-        const bool ok = big_candidate(o, u, bs, tmin, bs.index == prev, t);
-        offer(ok, t, bs.index, best, id);
-      }
-    }
-    const unsigned long long t_scan0 = RTOW_CLOCK();
-    // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
-    if (X_LDS && exhausted && (uint32_t)__popcll(__ballot(alive)) <= kSparseLanes)
-      scan_sparse(exact_lds, nk_lds, cand, P.n_geom_pad, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
-    else if (X_LDS) scan_regular<K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
-    else scan_regular<K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, best, id RTOW_PROF_ARG);
-    const unsigned long long t_scan1 = RTOW_CLOCK();
 #ifdef RTOW_PROFILE_COUNTERS
     uint32_t shade_draws = 0;
 #endif
-    if (alive) {
-      if (P.hit_id && first_sample && depth == P.max_depth) P.hit_id[accpix] = id;
-
-      float rr_ = 0.0f, rg_ = 0.0f, rb_ = 0.0f;
-      bool ended;
-      if (id < 0) {
-        shade_sky(u, tr, tg, tb, rr_, rg_, rb_);
-        ended = true;
+#if defined(RTOW_PROFILE_COUNTERS) || defined(RTOW_PROFILE_TIMELINE)
+    unsigned long long t_scan0 = 0, t_scan1 = 0;
+#define RTOW_STAMP(v) v = RTOW_CLOCK()
+#else
+#define RTOW_STAMP(v) do { } while (0)
+#endif
+    if (primary) {
+      // ================= PRIMARY iteration: the chunk's next n_gen paths, one per lane =================
+      // (pixel, sample) of lane's path: e counts samples from the first sample of the chunk's
+      // first pixel.  With spp >= chunk_max it overflows spp at most once.
+      const bool gen = lane < n_gen;
+      const uint32_t e = s_base + e_next + (gen ? lane : 0u);
+      uint32_t dp, sample;
+      if ((uint32_t)P.spp >= P.chunk_max) {
+        dp = e >= (uint32_t)P.spp ? 1u : 0u;
+        sample = e - (dp ? (uint32_t)P.spp : 0u);
       } else {
-        const SphereShade sh = P.shade[id];
-        f3 dn;
-#ifdef RTOW_PROFILE_COUNTERS
-        const uint32_t x0_before = g.x0;
-#endif
-        const bool scattered = shade_hit(sh, o, u, best, g, dn, tr, tg, tb);
-#ifdef RTOW_PROFILE_COUNTERS
-        shade_draws = (g.x0 - x0_before) * 0x144cbc89u;
-#endif
-        d = dn;
-        prev = id;
-        --depth;
-        ended = !scattered || depth <= 0;  // absorbed, or depth exhausted: black (raytracer.nim:8-9,16)
+        // e < 2 * chunk_max + spp and spp < chunk_max here: exact (2^32 / 1 does not fit inv_spp)
+        dp = P.spp == 1 ? e : __umulhi(e, P.inv_spp);
+        sample = e - dp * (uint32_t)P.spp;
       }
-      if (ended) {
-        acc_r += to_fix(rr_); acc_g += to_fix(rg_); acc_b += to_fix(rb_);
-        alive = false;
+      double* const rays = (double*)pool;   // the pool is empty during this iteration: its memory holds the rays
+      {
+        // The camera (19 doubles) is read from the kernel arguments here, every time: kept in scalar
+        // registers across the sphere scan it would push other values out into vector-register lanes.
+        typedef const double __attribute__((address_space(4)))* karg_ptr;
+        karg_ptr cf = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();   // TraceParams starts with cam: 19 doubles
+        asm volatile("" : "+s"(cf));
+        static_assert(offsetof(TraceParams, cam) == 0 && sizeof(CameraParams64) == 19 * sizeof(double), "camera layout");
+        uint32_t r = r_base;
+        int ci = (int)i_base - (int)dp;
+        while (ci < 0) { ci += P.W; --r; }
+        const int y = P.rows ? P.rows[r] : (int)r;
+        Stream g2 = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + P.sample_base);
+        // raytracer.nim:41-42: u before v, divisors W-1 and H-1, j counted from the bottom row
+        const double xi1 = (double)(draw_u32(g2) >> 8) * 0x1p-24, xi2 = (double)(draw_u32(g2) >> 8) * 0x1p-24;
+        const double cs = ((double)ci + xi1) / (double)(P.W - 1);
+        const double ct = ((double)(P.H - 1 - y) + xi2) / (double)(P.H - 1);
+        // randomInUnitDisk (basetypes.nim:130-134): x, y = rand(-1.0..1.0) = (k - 2^23) / 2^23 for a 24-bit draw k;
+        // x^2 + y^2 >= 1 is decided exactly in integers (binary64 evaluates the same sum without rounding)
+        int ax, ay;
+        do {
+          ax = (int)(draw_u32(g2) >> 8) - (1 << 23); ay = (int)(draw_u32(g2) >> 8) - (1 << 23);
+        } while ((long long)ax * ax + (long long)ay * ay >= (1ll << 46));
+        // getRay (camera.nim:34-39)
+        const double lens = cf[18];
+        const double rdx = lens * ((double)ax * 0x1p-23), rdy = lens * ((double)ay * 0x1p-23);
+        double o64[3], d64[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double off = cf[12 + k] * rdx + cf[15 + k] * rdy;
+          o64[k] = cf[0 + k] + off;
+          d64[k] = cf[3 + k] + cs * cf[6 + k] + ct * cf[9 + k] - cf[0 + k] - off;
+        }
+        // the |radius| >= 100 spheres never pass the screen (k = +inf): every lane tests them itself, in list
+        // order with the shrinking t_max (hittables.nim:84-88)
+        const double a64 = d64[0] * d64[0] + d64[1] * d64[1] + d64[2] * d64[2];   // length_squared (basetypes.nim:88)
+        double closest = INFINITY;
+        int pid = -1;
+        for (int k = 0; k < P.n_big; ++k) {
+          const int j = P.big[k].index;
+          double root;
+          if (RTOW_GUARDED(2, j, P.n_list) &&
+              sphere_hit_f64(o64[0], o64[1], o64[2], d64[0], d64[1], d64[2], a64, P.geom64[j], root) && !(closest < root)) {
+            closest = root;
+            pid = j;
+          }
+        }
+        rays[0 * 64 + lane] = o64[0]; rays[1 * 64 + lane] = o64[1]; rays[2 * 64 + lane] = o64[2];
+        rays[3 * 64 + lane] = d64[0]; rays[4 * 64 + lane] = d64[1]; rays[5 * 64 + lane] = d64[2];
+        pool[12 * 64 + lane] = g2.x0; pool[13 * 64 + lane] = g2.key1;   // the stream goes on in the hit's shading
+        cand.best[lane] = (unsigned long long)__double_as_longlong(closest);
+        pc.best_id[lane] = (uint32_t)(pid + 1);
+        const f3 so = {(float)o64[0], (float)o64[1], (float)o64[2]};
+        const f3 sd = {(float)d64[0], (float)d64[1], (float)d64[2]};
+        f3 su;
+        float tmin_unused;
+        segment_begin(sd, su, tmin_unused);
+        RTOW_COUNT(14, 1);
+        RTOW_STAMP(t_scan0);
+        // the screen runs on the binary32 roundings of the ray; survivors get the binary64 test
+        if (X_LDS) scan_regular<true, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc RTOW_PROF_ARG);
+        else scan_regular<true, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc RTOW_PROF_ARG);
+        RTOW_STAMP(t_scan1);
+      }
+      // ---- the camera rays' hits: sky ends the path (binary64, raytracer.nim:18-20), a hit scatters
+      const double t64 = __longlong_as_double((long long)cand.best[lane]);
+      const int pid = (int)pc.best_id[lane] - 1;
+      const lds_f64_ptr ray = pc.rays + lane;
+      const double ox = ray[0], oy = ray[64], oz = ray[128], dx = ray[192], dy = ray[256], dz = ray[320];
+      Stream g2 = {pool[12 * 64 + lane], pool[13 * 64 + lane]};
+      lds_order();   // every lane has read its ray before the pool entries below overwrite the rays
+      const uint32_t pix2 = p_base - dp;
+      uint32_t fr = 0, fg = 0, fb = 0;
+      bool sky = false, cont = false;
+      f3 p = {0, 0, 0}, dn = {0, 0, 1};
+      float ptr_ = 1.0f, ptg_ = 1.0f, ptb_ = 1.0f;
+      if (gen) {
+        if (P.hit_id && sample + P.sample_base == 0u && RTOW_GUARDED(3, pix2, (long long)P.n_rows * P.W)) P.hit_id[pix2] = pid;
+        if (pid < 0 || !RTOW_GUARDED(4, pid, P.n_list)) {
+          // unitVector(r.dir).y = dir.y / length(dir); t = 0.5 (y + 1); (1 - t) * 1 + t * colour
+          const double uy = dy / sqrt(dx * dx + dy * dy + dz * dz);
+          const double ts = 0.5 * (uy + 1.0);
+          const double w1 = (1.0 - ts) * 1.0;
+          fr = to_fix64(w1 + ts * 0.5); fg = to_fix64(w1 + ts * 0.7); fb = to_fix64(w1 + ts * 1.0);
+          sky = true;
+        } else {
+          // rec.p = r.at(t) = orig + t * dir (basetypes.nim:170), rounded to binary32: the path goes on from
+          // there, with the binary32 unit direction of the rounded camera ray
+          p = {(float)(ox + t64 * dx), (float)(oy + t64 * dy), (float)(oz + t64 * dz)};
+          const f3 sd = {(float)dx, (float)dy, (float)dz};
+          f3 su;
+          float tmin_unused;
+          segment_begin(sd, su, tmin_unused);
+          const SphereShade sh = P.shade[pid];
+          cont = shade_at(sh, p, su, g2, dn, ptr_, ptg_, ptb_) && P.max_depth > 1;
+        }
+      }
+      flush_sums(P.accum, sums, sky, pix2, fr, fg, fb, lane);
+      const uint64_t m = __ballot(cont);
+      if (cont) {
+        const uint32_t slot = lanes_below(m);
+        pool[(kPoolO + 0) * 64 + slot] = __float_as_uint(p.x); pool[(kPoolO + 1) * 64 + slot] = __float_as_uint(p.y);
+        pool[(kPoolO + 2) * 64 + slot] = __float_as_uint(p.z); pool[(kPoolD + 0) * 64 + slot] = __float_as_uint(dn.x);
+        pool[(kPoolD + 1) * 64 + slot] = __float_as_uint(dn.y); pool[(kPoolD + 2) * 64 + slot] = __float_as_uint(dn.z);
+        pool[(kPoolT + 0) * 64 + slot] = __float_as_uint(ptr_); pool[(kPoolT + 1) * 64 + slot] = __float_as_uint(ptg_);
+        pool[(kPoolT + 2) * 64 + slot] = __float_as_uint(ptb_);
+        pool[kPoolX0 * 64 + slot] = g2.x0; pool[kPoolKey1 * 64 + slot] = g2.key1;
+        pool[kPoolPix * 64 + slot] = pix2; pool[kPoolPrev * 64 + slot] = (uint32_t)pid;
+      }
+      pool_n = (uint32_t)__popcll(m);
+      pool_head = 0;
+      e_next += n_gen;
+      nseg_primary += n_gen;
+      lds_order();   // the entries are read by other lanes of this wave
+    } else {
+      // ================= BOUNCE iteration: every path in flight traces its next segment in binary32 =================
+      f3 u = {0, 0, 1};
+      float tmin = 0.0f;
+      {
+        float best = INFINITY;
+        int id = -1;
+        if (alive) {
+          ++nseg;
+          segment_begin(d, u, tmin);
+          for (int k = 0; k < P.n_big; ++k) {
+            const BigSphere bs = P.big[k];
+            float t;
+            const bool ok = big_candidate(o, u, bs, tmin, bs.index == prev, t);
+            offer(ok, t, bs.index, best, id);
+          }
+        }
+        cand.best[lane] = hit_key(best, id);   // what the binary64 spheres left; read back after the last drain
+      }
+      RTOW_COUNT(4, __popcll(__ballot(alive)));
+      RTOW_STAMP(t_scan0);
+      // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
+      if (X_LDS && exhausted && (uint32_t)__popcll(__ballot(alive)) <= kSparseLanes)
+        scan_sparse(exact_lds, nk_lds, cand, P.n_geom_pad, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      else if (X_LDS) scan_regular<false, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      else scan_regular<false, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      RTOW_STAMP(t_scan1);
+      if (alive) {
+        // world.hit + scatter (raytracer.nim:11-16)
+        const unsigned long long key = cand.best[lane];
+        const float best = __uint_as_float((uint32_t)(key >> 32));
+        const int id = hit_key_id(key);
+        float rr_ = 0.0f, rg_ = 0.0f, rb_ = 0.0f;
+        bool ended;
+        if (id < 0 || !RTOW_GUARDED(5, id, P.n_list)) {
+          shade_sky(u, tr, tg, tb, rr_, rg_, rb_);
+          ended = true;
+        } else {
+          const SphereShade sh = P.shade[id];
+          f3 dn;
+#ifdef RTOW_PROFILE_COUNTERS
+          const uint32_t x0_before = g.x0;
+#endif
+          const bool scattered = shade_hit(sh, o, u, best, g, dn, tr, tg, tb);
+#ifdef RTOW_PROFILE_COUNTERS
+          shade_draws = (g.x0 - x0_before) * 0x144cbc89u;
+#endif
+          d = dn;
+          prev = id;
+          --depth;
+          ended = !scattered || depth <= 0;  // absorbed, or depth exhausted: black (raytracer.nim:8-9,16)
+        }
+        if (ended) {
+          acc_r += to_fix(rr_); acc_g += to_fix(rg_); acc_b += to_fix(rb_);
+          alive = false;
+        }
       }
     }
     RTOW_COUNT(3, 1);
 #ifdef RTOW_PROFILE_COUNTERS
     {
-      uint32_t m = shade_draws;
-      for (int off = 32; off > 0; off >>= 1) { const uint32_t t_ = __shfl_xor(m, off, 64); m = t_ > m ? t_ : m; }
-      RTOW_COUNT(11, m / 3u);   // rejection-loop trips of the slowest lane
+      uint32_t m_ = shade_draws;
+      for (int off = 32; off > 0; off >>= 1) { const uint32_t t_ = __shfl_xor(m_, off, 64); m_ = t_ > m_ ? t_ : m_; }
+      RTOW_COUNT(11, m_ / 3u);   // rejection-loop trips of the slowest lane
     }
 #endif
 #ifdef RTOW_PROFILE_TIMELINE
@@ -671,11 +876,14 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       g_wave_times[12 * wave_id + 11] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    RTOW_COUNT(5, t_seg - t_refill);           // refill
-    RTOW_COUNT(6, t_scan0 - t_seg);            // normalise + binary64 spheres
+#ifdef RTOW_PROFILE_COUNTERS
+    RTOW_COUNT(5, t_seg - t_refill);           // hand-out, chunk fetch
+    RTOW_COUNT(6, t_scan0 - t_seg);            // ray set-up: camera rays / normalise, binary64 spheres
     RTOW_COUNT(7, t_scan1 - t_scan0);          // scan (filter + exact tests)
     RTOW_COUNT(8, RTOW_CLOCK() - t_scan1);     // shading
-    (void)t_refill; (void)t_seg; (void)t_scan0; (void)t_scan1;
+    RTOW_COUNT(primary ? 13 : 15, RTOW_CLOCK() - t_refill);   // whole iteration, by kind
+#endif
+    (void)t_refill; (void)t_seg;
   }
 
 #ifdef RTOW_PROFILE_TIMELINE
@@ -691,7 +899,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   }
 #endif
   // ray-segment count: wave reduction, one atomic per wave
-  const unsigned long long total = wave_sum(nseg);
+  const unsigned long long total = wave_sum(nseg) + nseg_primary;
   if (lane == 0) atomicAdd(P.seg_counter, total);
 }
 
@@ -702,9 +910,13 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
   if (i < n_channels) rgb[i] = (uint8_t)quantise_fix(accum[i], spp);
 }
 
-static size_t stack_lds_bytes() { return sizeof(uint32_t) * (kTraceThreads / 64) * (kCandWords + kPoolFields * 64 + kSumCacheDwords); }
-static size_t k_lds_bytes(int n_geom_pad) { return stack_lds_bytes() + sizeof(float) * (size_t)(n_geom_pad + 4); }
-static size_t kx_lds_bytes(int n_geom_pad) { return k_lds_bytes(n_geom_pad) + sizeof(float4) * (size_t)n_geom_pad; }
+static size_t wave_lds_bytes(bool short_entries) {
+  return sizeof(uint32_t) * (kTraceThreads / 64) * (short_entries ? WaveLds<true>::kTotal : WaveLds<false>::kTotal);
+}
+static size_t k_lds_bytes(int n_geom_pad) { return wave_lds_bytes(false) + sizeof(float) * (size_t)(n_geom_pad + 4); }
+static size_t kx_lds_bytes(int n_geom_pad) {
+  return wave_lds_bytes(true) + sizeof(float) * (size_t)(n_geom_pad + 4) + sizeof(float4) * (size_t)n_geom_pad;
+}
 
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream) {
   if (p.n_geom_pad <= kMaxSpheresExactInLds)
@@ -714,7 +926,7 @@ void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream) {
     hipLaunchKernelGGL((rtow_trace_kernel<true, false>), dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
                        stream, p);
   else
-    hipLaunchKernelGGL((rtow_trace_kernel<false, false>), dim3(grid_blocks), dim3(kTraceThreads), stack_lds_bytes(), stream, p);
+    hipLaunchKernelGGL((rtow_trace_kernel<false, false>), dim3(grid_blocks), dim3(kTraceThreads), wave_lds_bytes(false), stream, p);
 }
 
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
@@ -852,6 +1064,13 @@ void launch_arithmetic_selftest(unsigned long long* mismatches, hipStream_t stre
   hipLaunchKernelGGL(arithmetic_selftest_kernel, dim3(256 * 8), dim3(256), 0, stream, mismatches);
 }
 
+#ifdef RTOW_GUARD
+extern "C" int rtow_debug_guard(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guard), sizeof(g_guard)) != hipSuccess) return -2;
+  return 0;
+}
+#endif
+
 #ifdef RTOW_PROFILE_COUNTERS
 extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -2;
@@ -876,7 +1095,7 @@ int trace_blocks_per_cu(int n_geom_pad) {
   else if (n_geom_pad <= kMaxSpheresKInLds)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, false>, kTraceThreads, k_lds_bytes(n_geom_pad));
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false, false>, kTraceThreads, stack_lds_bytes());
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false, false>, kTraceThreads, wave_lds_bytes(false));
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }

@@ -115,6 +115,12 @@ struct CameraParams {
   float lens_radius;
 };
 
+// the same fields in binary64, as initCamera computes them (camera.nim:12-31): 19 doubles, in this order
+struct CameraParams64 {
+  double origin[3], llc[3], hor[3], ver[3], u[3], v[3];
+  double lens_radius;
+};
+
 // Pixel jitter (raytracer.nim:41-42, u drawn before v) and thin-lens ray (camera.nim:34-39 with
 // randomInUnitDisk, basetypes.nim:130-134).  i = column, j = row counted from the bottom.
 RTOW_HD void camera_ray(const CameraParams& cam, int i, int j, int W, int H, Stream& g, f3& o, f3& d) {
@@ -251,9 +257,8 @@ RTOW_HD void shade_sky(f3 u, float tr, float tg, float tb, float& rr, float& rg,
 // Hit record (hitrecord.nim:73-77) + scatter (hitrecord.nim:82-132) at distance t along unit u.
 // Updates origin, direction and throughput; returns false when the path is absorbed (Metal
 // scattering below the surface, hitrecord.nim:99), in which case it contributes black.
-RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3& d_next,
-                       float& tr, float& tg, float& tb) {
-  const f3 p = {fmaf(t, u.x, o.x), fmaf(t, u.y, o.y), fmaf(t, u.z, o.z)};
+// shade_at: the same at a hit point p that the caller has already computed.
+RTOW_HD bool shade_at(const SphereShade& s, f3 p, f3 u, Stream& g, f3& d_next, float& tr, float& tg, float& tb) {
   f3 n = {(p.x - s.cx) * s.inv_r, (p.y - s.cy) * s.inv_r, (p.z - s.cz) * s.inv_r};
   const bool front = dot3(u, n) < 0.0f;  // setFaceNormal, hitrecord.nim:51-53
   if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
@@ -297,15 +302,27 @@ RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3
     }
     tr *= s.ar; tg *= s.ag; tb *= s.ab;
   }
-  o = p;
   d_next = nd;
   return true;
+}
+
+RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3& d_next,
+                       float& tr, float& tg, float& tb) {
+  const f3 p = {fmaf(t, u.x, o.x), fmaf(t, u.y, o.y), fmaf(t, u.z, o.z)};
+  o = p;   // the scattered ray starts at the hit point whether or not it survives
+  return shade_at(s, p, u, g, d_next, tr, tg, tb);
 }
 
 // one sample's channel radiance -> fixed point (30 fractional bits)
 RTOW_HD uint32_t to_fix(float c) {
   c = fminf(fmaxf(c, 0.0f), kRadianceClamp);
   return (uint32_t)(c * kFixOne);
+}
+
+// the same for a sample evaluated in binary64 (the sky colour of a primary miss)
+RTOW_HD uint32_t to_fix64(double c) {
+  c = c < 0.0 ? 0.0 : (c > (double)kRadianceClamp ? (double)kRadianceClamp : c);
+  return (uint32_t)(c * kFixOneD);
 }
 
 // writeColor (raytracer.nim:22-28) on a fixed-point channel sum: mean, sqrt gamma,

@@ -53,13 +53,14 @@ class HittablesList:
     __iter__ = items
 
     def flatten(self):
-        """SoA arrays in list order: dict of float32/uint8 arrays for rtow_set_scene."""
+        """SoA arrays in list order: dict of float64/uint8 arrays for rtow_set_scene_f64 (Nim `float`
+        is binary64; the library rounds what it needs in binary32 itself)."""
         n = len(self._data)
         out = {
-            "center_x": np.empty(n, np.float32), "center_y": np.empty(n, np.float32),
-            "center_z": np.empty(n, np.float32), "radius": np.empty(n, np.float32),
-            "kind": np.empty(n, np.uint8), "albedo": np.empty((n, 3), np.float32),
-            "fuzz": np.empty(n, np.float32), "ir": np.empty(n, np.float32),
+            "center_x": np.empty(n, np.float64), "center_y": np.empty(n, np.float64),
+            "center_z": np.empty(n, np.float64), "radius": np.empty(n, np.float64),
+            "kind": np.empty(n, np.uint8), "albedo": np.empty((n, 3), np.float64),
+            "fuzz": np.empty(n, np.float64), "ir": np.empty(n, np.float64),
         }
         for j, h in enumerate(self._data):
             s = h.hSphere

@@ -12,14 +12,14 @@ struct Camera {  // camera.nim:4-10
   double lensRadius = 0;
   Vec3 u, v, w;
 
-  rtow_camera flat() const {  // the eight fields rounded to binary32
-    rtow_camera c;
+  rtow_camera_f64 flat() const {  // the eight fields as computed, for rtow_set_camera_f64
+    rtow_camera_f64 c;
     for (int i = 0; i < 3; ++i) {
-      c.origin[i] = (float)origin[i]; c.lower_left[i] = (float)lowerLeftCorner[i];
-      c.horizontal[i] = (float)horizontal[i]; c.vertical[i] = (float)vertical[i];
-      c.u[i] = (float)u[i]; c.v[i] = (float)v[i]; c.w[i] = (float)w[i];
+      c.origin[i] = origin[i]; c.lower_left[i] = lowerLeftCorner[i];
+      c.horizontal[i] = horizontal[i]; c.vertical[i] = vertical[i];
+      c.u[i] = u[i]; c.v[i] = v[i]; c.w[i] = w[i];
     }
-    c.lens_radius = (float)lensRadius;
+    c.lens_radius = lensRadius;
     return c;
   }
 };

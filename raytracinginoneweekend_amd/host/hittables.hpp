@@ -1,5 +1,5 @@
 // The scene container with the reference's interface (hittables.nim:3-73) and the flattening to
-// the structure-of-arrays form rtow_set_scene uploads.
+// the structure-of-arrays form rtow_set_scene_f64 uploads.
 #pragma once
 #include <cassert>
 #include <cstdint>
@@ -23,7 +23,7 @@ class HittablesList {
   std::vector<Hittable>::const_iterator end() const { return data_.end(); }
 
   struct Flat {
-    std::vector<float> cx, cy, cz, radius, albedo, fuzz, ir;
+    std::vector<double> cx, cy, cz, radius, albedo, fuzz, ir;   // Nim float = binary64
     std::vector<uint8_t> kind;
   };
   // list order is kept: index i here is insertion index i, which decides ties (hittables.nim:84-88)
@@ -31,14 +31,14 @@ class HittablesList {
     Flat f;
     for (const Hittable& h : data_) {
       const Sphere& s = h.hSphere;
-      f.cx.push_back((float)s.center[0]); f.cy.push_back((float)s.center[1]); f.cz.push_back((float)s.center[2]);
-      f.radius.push_back((float)s.radius);
+      f.cx.push_back(s.center[0]); f.cy.push_back(s.center[1]); f.cz.push_back(s.center[2]);
+      f.radius.push_back(s.radius);
       f.kind.push_back((uint8_t)s.mat.kind);
       const Color a = s.mat.kind == mkLambertian ? s.mat.mLambertian.albedo
                       : s.mat.kind == mkMetal    ? s.mat.mMetal.albedo : color(1, 1, 1);
-      for (int c = 0; c < 3; ++c) f.albedo.push_back((float)a[c]);
-      f.fuzz.push_back(s.mat.kind == mkMetal ? (float)s.mat.mMetal.fuzz : 0.0f);
-      f.ir.push_back(s.mat.kind == mkDielectric ? (float)s.mat.mDielectric.ir : 1.0f);
+      for (int c = 0; c < 3; ++c) f.albedo.push_back(a[c]);
+      f.fuzz.push_back(s.mat.kind == mkMetal ? s.mat.mMetal.fuzz : 0.0);
+      f.ir.push_back(s.mat.kind == mkDielectric ? s.mat.mDielectric.ir : 1.0);
     }
     return f;
   }

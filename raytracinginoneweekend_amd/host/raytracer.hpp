@@ -37,10 +37,10 @@ inline std::vector<uint8_t> render(const Image& img, const std::string& f, const
   std::vector<uint8_t> rgb((size_t)img.width * (size_t)img.height * 3);
   try {
     const HittablesList::Flat s = world.flatten();
-    check(rtow_set_scene(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
-                         s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene");
-    const rtow_camera cam = camera.flat();
-    check(rtow_set_camera(ctx, &cam), "rtow_set_camera");
+    check(rtow_set_scene_f64(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
+                         s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene_f64");
+    const rtow_camera_f64 cam = camera.flat();
+    check(rtow_set_camera_f64(ctx, &cam), "rtow_set_camera_f64");
     check(rtow_render(ctx, img.width, img.height, samplesPerPixel, maxDepth, seed, nullptr, img.height,
                       rgb.data(), nullptr, nullptr), "rtow_render");
     if (stats) check(rtow_get_stats(ctx, stats), "rtow_get_stats");
@@ -74,14 +74,14 @@ inline std::vector<uint8_t> renderMulti(const Image& img, const std::string& f, 
   auto destroyAll = [&]() { for (rtow_ctx* c : ctxs) rtow_destroy(c); };
   try {
     const HittablesList::Flat s = world.flatten();
-    const rtow_camera cam = camera.flat();
+    const rtow_camera_f64 cam = camera.flat();
     for (int device : devices) {
       rtow_ctx* ctx = nullptr;
       check(rtow_create(device, &ctx), "rtow_create");
       ctxs.push_back(ctx);
-      check(rtow_set_scene(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
-                           s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene");
-      check(rtow_set_camera(ctx, &cam), "rtow_set_camera");
+      check(rtow_set_scene_f64(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
+                           s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene_f64");
+      check(rtow_set_camera_f64(ctx, &cam), "rtow_set_camera_f64");
     }
     check(rtow_render_multi(ctxs.data(), (int)ctxs.size(), img.width, img.height, samplesPerPixel, maxDepth, seed, 4,
                             rgb.data(), raySegments), "rtow_render_multi");

@@ -52,23 +52,31 @@ class Renderer:
     def __exit__(self, *exc):
         self.close()
 
-    def setWorld(self, world):
+    def setWorld(self, world, binary32=False):
+        """Upload a HittablesList (or its flattened dict of arrays).  The values go to the library in
+        binary64 (rtow_set_scene_f64); binary32=True rounds them first and uses rtow_set_scene."""
         if isinstance(world, HittablesList):
             world = world.flatten()
-        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
-        cx, cy, cz, rad = f32(world["center_x"]), f32(world["center_y"]), f32(world["center_z"]), f32(world["radius"])
+        ft = np.float32 if binary32 else np.float64
+        fa = lambda a: np.ascontiguousarray(a, dtype=ft)  # noqa: E731
+        cx, cy, cz, rad = fa(world["center_x"]), fa(world["center_y"]), fa(world["center_z"]), fa(world["radius"])
         kind = np.ascontiguousarray(world["kind"], dtype=np.uint8)
-        albedo, fuzz, ir = f32(world["albedo"]), f32(world["fuzz"]), f32(world["ir"])
+        albedo, fuzz, ir = fa(world["albedo"]), fa(world["fuzz"]), fa(world["ir"])
         n = len(rad)
         if not (len(cx) == len(cy) == len(cz) == len(kind) == len(fuzz) == len(ir) == n and albedo.shape == (n, 3)):
             raise ValueError("setWorld: arrays of unequal length")
         p = lambda a: a.ctypes.data if n else None  # noqa: E731
-        self._check(self._lib.rtow_set_scene(self._h, n, p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo), p(fuzz), p(ir)))
+        call = self._lib.rtow_set_scene if binary32 else self._lib.rtow_set_scene_f64
+        self._check(call(self._h, n, p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo), p(fuzz), p(ir)))
         self.n_spheres = n
 
     def setCamera(self, camera):
+        """Upload a Camera (binary64 fields) or a ready _lib.CameraStruct / CameraStruct64."""
         s = camera.to_struct() if isinstance(camera, Camera) else camera
-        self._check(self._lib.rtow_set_camera(self._h, C.byref(s)))
+        if isinstance(s, _lib.CameraStruct):
+            self._check(self._lib.rtow_set_camera(self._h, C.byref(s)))
+        else:
+            self._check(self._lib.rtow_set_camera_f64(self._h, C.byref(s)))
 
     @staticmethod
     def _rows(rows, height):

@@ -17,8 +17,12 @@ n = len(scene)
 rows = None if a.share == 1 else multigpu.tile_rows(800, a.share, 0, 4)
 rs = []
 for path in a.libs:
-    r = R.Renderer(0, lib=_lib.load(os.path.abspath(path)))
-    r.setWorld(scene); r.setCamera(R.bookCamera(1.5))
+    L = _lib.load(os.path.abspath(path), strict=False)
+    r = R.Renderer(0, lib=L)
+    if hasattr(L, "rtow_set_scene_f64"):
+        r.setWorld(scene); r.setCamera(R.bookCamera(1.5))
+    else:   # a build from before the binary64 scene / camera entry points
+        r.setWorld(scene, binary32=True); r.setCamera(R.bookCamera(1.5).to_struct(binary32=True))
     r.renderAsync(1200, 800, 8, 50); r.sync()
     rs.append(r)
 times = [[] for _ in rs]; seg = [0] * len(rs)

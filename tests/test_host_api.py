@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "rtow.h")).read()
-    declared = sorted(set(re.findall(r"\b(rtow_[a-z_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(rtow_[a-z0-9_]+)\s*\(", header)))
     assert declared == sorted(_lib.SYMBOLS)
     L = _lib.lib()
     for name in declared:
@@ -111,9 +111,9 @@ def test_hittables_list_interface():
         h.add(s)
     assert h.size > 22
     f = h.flatten()
-    assert f["radius"].dtype == np.float32 and f["kind"].dtype == np.uint8 and f["albedo"].shape == (22, 3)
+    assert f["radius"].dtype == np.float64 and f["kind"].dtype == np.uint8 and f["albedo"].shape == (22, 3)
     assert f["radius"][1] == -2.0 and f["kind"][1] == HR.mkDielectric and f["ir"][1] == 1.5
-    assert np.allclose(f["albedo"][0], [0.1, 0.2, 0.3]) and f["fuzz"][0] == np.float32(0.4)
+    assert np.allclose(f["albedo"][0], [0.1, 0.2, 0.3]) and f["fuzz"][0] == 0.4
     assert HT.initHittables(0).flatten()["radius"].shape == (0,)
     with pytest.raises(TypeError):
         HR.initMaterial(object())
@@ -128,7 +128,9 @@ def test_camera_host_equals_oracle(oracle):
             assert list(getattr(o, a)) == list(getattr(c, b))
         assert o.lens_radius == c.lensRadius
         s = c.to_struct()
-        assert s.origin[0] == 13.0 and abs(s.lens_radius - 0.05) < 1e-8
+        assert isinstance(s, _lib.CameraStruct64) and list(s.lower_left) == list(o.lower_left) and s.lens_radius == 0.05
+        s = c.to_struct(binary32=True)
+        assert isinstance(s, _lib.CameraStruct) and s.origin[0] == 13.0 and abs(s.lens_radius - 0.05) < 1e-8
     with pytest.raises(TypeError):
         cam_mod.initCamera(B.point(0, 0, 0), B.point(0, 0, -1), B.vec3(0, 1, 0), 90, 2.0)
 
