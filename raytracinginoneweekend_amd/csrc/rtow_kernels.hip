@@ -20,8 +20,10 @@
 namespace rtow {
 
 #ifdef RTOW_PROFILE_COUNTERS
-// debug build only: [0] wave-level group slow-path entries, [1] wave-level candidate evaluations,
-// [2] lane-level candidate evaluations, [3] wave iterations, [4] lane iterations (alive lanes)
+// debug build only, summed over waves: [0] lanes entering a group's push path, [3] wave iterations, [4] lanes with a
+// path over the BOUNCE iterations, [14] PRIMARY iterations, [9] groups with a survivor in some lane, [10] / [12]
+// rounds of binary32 / binary64 exact tests, [11] rejection-loop trips of the slowest lane; clock cycles:
+// [5] hand-out, [1] [2] [13] set-up, scan, shading of PRIMARY iterations, [6] [7] [8] of BOUNCE iterations, [15] all
 __device__ unsigned long long g_prof[16];
 
 // wave-local accumulation (values are wave-uniform), flushed once when the wave retires
@@ -415,25 +417,37 @@ static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long
   return v;
 }
 
-// A lane keeps the fixed-point radiance sums of the pixel it is working on in registers (about eight
-// paths in a row belong to the same pixel at spp 500) and hands them over when it moves on to another
-// pixel.  The lanes of a wave change pixel a few at a time, so the sums of a pixel are collected in a
-// small per-wave cache in LDS first - four direct-mapped slots of three 64-bit words, filled with LDS
-// atomics - and a slot goes to the frame (three 64-bit global atomics) when another pixel claims it
-// or the wave ends: one set of global atomics per pixel and wave instead of one per lane.  Integer
-// sums do not depend on the order they arrive in.  (A shuffle reduction over the lanes of a pixel does
-// the same at ~100 VALU instructions per round; the LDS atomics cost the VALU one instruction each.)
+// A path that ends with light (the sky) adds its fixed-point radiance to its pixel.  The paths of a wave
+// belong to a handful of pixels at a time (a chunk is a run of consecutive samples), so the sums are
+// collected in a small per-wave cache in LDS first - four direct-mapped slots of three 64-bit words,
+// filled with LDS atomics - and a slot goes to the frame (three 64-bit global atomics) when another
+// pixel claims it or the wave ends: one set of global atomics per pixel and wave.  Integer sums do not
+// depend on the order they arrive in.  (Sums kept per lane in registers and handed over when the lane
+// changes pixel cost six registers per lane in a kernel that spills; a shuffle reduction over the
+// lanes of a pixel costs ~100 VALU instructions per round; the LDS atomics cost the VALU one each.)
 constexpr uint32_t kSumSlots = 4;
 constexpr uint32_t kSumCacheDwords = 32;   // per wave: kSumSlots * 3 words of 8 bytes, padded to 128 bytes
 constexpr uint32_t kNoPixel = 0xffffffffu;
 
+// The tags are wave-uniform scalars on purpose.  (Kept in the lanes of a vector register they are only
+// safe while that register is never spilled inside a divergent region: a spill stores the active lanes
+// only, and the lanes that hold the tags need not be among them.)
 struct SumCache {
   lds_u64_ptr words;             // this wave's kSumSlots * 3 words
-  uint32_t tags;                 // lane s < kSumSlots: the pixel slot s holds (one VGPR; scalar registers are scarce here)
+  uint32_t tag[kSumSlots];       // the pixel each slot holds
 #ifdef RTOW_GUARD
   long long n_pixels;
 #endif
 };
+static_assert(kSumSlots == 4, "tag_of / set_tag select among four scalars");
+
+static __device__ __forceinline__ uint32_t tag_of(const SumCache& c, uint32_t slot) {
+  return slot == 0u ? c.tag[0] : slot == 1u ? c.tag[1] : slot == 2u ? c.tag[2] : c.tag[3];
+}
+static __device__ __forceinline__ void set_tag(SumCache& c, uint32_t slot, uint32_t pix) {
+  c.tag[0] = slot == 0u ? pix : c.tag[0]; c.tag[1] = slot == 1u ? pix : c.tag[1];
+  c.tag[2] = slot == 2u ? pix : c.tag[2]; c.tag[3] = slot == 3u ? pix : c.tag[3];
+}
 
 static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum, const SumCache& c, uint32_t slot,
                                                        uint32_t pix, uint32_t lane) {
@@ -447,25 +461,24 @@ static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum
   lds_order();
 }
 
-// Must be called by all 64 lanes together; lanes with `want` set hand over (accpix, acc_*).
+// Must be called by all 64 lanes together; lanes with `want` set add (acc_r, acc_g, acc_b) to pixel accpix.
 static __device__ __forceinline__ void flush_sums(unsigned long long* accum, SumCache& c, bool want, uint32_t accpix,
-                                                  unsigned long long acc_r, unsigned long long acc_g,
-                                                  unsigned long long acc_b, uint32_t lane) {
+                                                  uint32_t acc_r, uint32_t acc_g, uint32_t acc_b, uint32_t lane) {
   uint64_t todo = __ballot(want);
   while (todo != 0) {
     const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
     const uint32_t pix = (uint32_t)__builtin_amdgcn_readlane((int)accpix, (int)leader);
     const uint32_t slot = pix & (kSumSlots - 1u);
-    const uint32_t held = (uint32_t)__builtin_amdgcn_readlane((int)c.tags, (int)slot);
+    const uint32_t held = tag_of(c, slot);
     if (held != pix) {
       if (held != kNoPixel) sum_cache_evict(accum, c, slot, held, lane);
-      c.tags = lane == slot ? pix : c.tags;
+      set_tag(c, slot, pix);
     }
     const bool mine = want && accpix == pix;
     if (mine) {
-      __hip_atomic_fetch_add(c.words + 3u * slot + 0u, acc_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      __hip_atomic_fetch_add(c.words + 3u * slot + 1u, acc_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      __hip_atomic_fetch_add(c.words + 3u * slot + 2u, acc_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __hip_atomic_fetch_add(c.words + 3u * slot + 0u, (unsigned long long)acc_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __hip_atomic_fetch_add(c.words + 3u * slot + 1u, (unsigned long long)acc_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __hip_atomic_fetch_add(c.words + 3u * slot + 2u, (unsigned long long)acc_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     todo &= ~__ballot(mine);
   }
@@ -473,10 +486,10 @@ static __device__ __forceinline__ void flush_sums(unsigned long long* accum, Sum
 
 static __device__ __forceinline__ void sum_cache_drain(unsigned long long* accum, SumCache& c, uint32_t lane) {
   for (uint32_t slot = 0; slot < kSumSlots; ++slot) {
-    const uint32_t held = (uint32_t)__builtin_amdgcn_readlane((int)c.tags, (int)slot);
+    const uint32_t held = c.tag[slot];
     if (held != kNoPixel) sum_cache_evict(accum, c, slot, held, lane);
+    c.tag[slot] = kNoPixel;
   }
-  c.tags = kNoPixel;
 }
 
 // fields of a pool entry: a path whose primary segment hit something and scattered
@@ -522,7 +535,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     uint32_t* const mine = wave_lds + L::kSums;
     if (lane < kSumCacheDwords) mine[lane] = 0u;   // read back only by this wave, in order
     sums.words = (lds_u64_ptr)(unsigned long long*)mine;
-    sums.tags = kNoPixel;
+    for (uint32_t k = 0; k < kSumSlots; ++k) sums.tag[k] = kNoPixel;
 #ifdef RTOW_GUARD
     sums.n_pixels = (long long)P.n_rows * P.W;
 #endif
@@ -556,10 +569,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   float tr = 0, tg = 0, tb = 0;
   Stream g = {0, 0};
   int depth = 0, prev = -1;
-  // per lane: radiance sums of the pixel it is working on
-  uint32_t accpix = 0xffffffffu;
-  unsigned long long acc_r = 0, acc_g = 0, acc_b = 0;
-  uint32_t nseg = 0;
+  uint32_t pix = 0;                   // its pixel (index in the row list's image)
+  unsigned long long nseg_bounce = 0; // wave-uniform: later segments traced by this wave
   float my_paths = 0.0f;              // paths this wave has been handed so far
   const float inv_waves = 1.0f / (float)P.n_waves;
   RTOW_PROF_DECL;
@@ -580,11 +591,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         const uint32_t cnt = (uint32_t)__popcll(need);
         const bool take = !alive && rank < avail;
         const uint32_t entry = take ? pool_head + rank : 0u;
-        const uint32_t pix_local = pool[kPoolPix * 64 + entry];
-        // a lane that moves on to another pixel hands its sums over first
-        flush_sums(P.accum, sums, take && accpix != pix_local && accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
         if (take) {
-          if (accpix != pix_local) { accpix = pix_local; acc_r = acc_g = acc_b = 0; }
+          pix = pool[kPoolPix * 64 + entry];
           o.x = __uint_as_float(pool[(kPoolO + 0) * 64 + entry]); o.y = __uint_as_float(pool[(kPoolO + 1) * 64 + entry]);
           o.z = __uint_as_float(pool[(kPoolO + 2) * 64 + entry]); d.x = __uint_as_float(pool[(kPoolD + 0) * 64 + entry]);
           d.y = __uint_as_float(pool[(kPoolD + 1) * 64 + entry]); d.z = __uint_as_float(pool[(kPoolD + 2) * 64 + entry]);
@@ -810,7 +818,6 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         float best = INFINITY;
         int id = -1;
         if (alive) {
-          ++nseg;
           segment_begin(d, u, tmin);
           for (int k = 0; k < P.n_big; ++k) {
             const BigSphere bs = P.big[k];
@@ -821,6 +828,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         }
         cand.best[lane] = hit_key(best, id);   // what the binary64 spheres left; read back after the last drain
       }
+      nseg_bounce += (unsigned long long)__popcll(__ballot(alive));
       RTOW_COUNT(4, __popcll(__ballot(alive)));
       RTOW_STAMP(t_scan0);
       // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
@@ -829,6 +837,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       else if (X_LDS) scan_regular<false, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
       else scan_regular<false, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
       RTOW_STAMP(t_scan1);
+      // A path that ends adds its radiance to its pixel right away, through the wave's cache of pixel sums
+      // (paths that end absorbed or at the depth limit are black and add nothing).
+      uint32_t fr = 0, fg = 0, fb = 0;
       if (alive) {
         // world.hit + scatter (raytracer.nim:11-16)
         const unsigned long long key = cand.best[lane];
@@ -855,10 +866,11 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           ended = !scattered || depth <= 0;  // absorbed, or depth exhausted: black (raytracer.nim:8-9,16)
         }
         if (ended) {
-          acc_r += to_fix(rr_); acc_g += to_fix(rg_); acc_b += to_fix(rb_);
+          fr = to_fix(rr_); fg = to_fix(rg_); fb = to_fix(rb_);
           alive = false;
         }
       }
+      flush_sums(P.accum, sums, (fr | fg | fb) != 0u, pix, fr, fg, fb, lane);
     }
     RTOW_COUNT(3, 1);
 #ifdef RTOW_PROFILE_COUNTERS
@@ -877,11 +889,11 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     }
 #endif
 #ifdef RTOW_PROFILE_COUNTERS
-    RTOW_COUNT(5, t_seg - t_refill);           // hand-out, chunk fetch
-    RTOW_COUNT(6, t_scan0 - t_seg);            // ray set-up: camera rays / normalise, binary64 spheres
-    RTOW_COUNT(7, t_scan1 - t_scan0);          // scan (filter + exact tests)
-    RTOW_COUNT(8, RTOW_CLOCK() - t_scan1);     // shading
-    RTOW_COUNT(primary ? 13 : 15, RTOW_CLOCK() - t_refill);   // whole iteration, by kind
+    RTOW_COUNT(5, t_seg - t_refill);                    // hand-out, chunk fetch (both kinds of iteration)
+    RTOW_COUNT(primary ? 1 : 6, t_scan0 - t_seg);       // ray set-up: camera rays + binary64 spheres / normalise + binary64 spheres
+    RTOW_COUNT(primary ? 2 : 7, t_scan1 - t_scan0);     // scan (filter + exact tests)
+    RTOW_COUNT(primary ? 13 : 8, RTOW_CLOCK() - t_scan1);  // shading (+ pool entries)
+    RTOW_COUNT(15, RTOW_CLOCK() - t_refill);            // whole iteration
 #endif
     (void)t_refill; (void)t_seg;
   }
@@ -889,7 +901,6 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 #ifdef RTOW_PROFILE_TIMELINE
   if (lane == 0 && wave_id < 16384) g_wave_times[12 * wave_id + 10] = __builtin_amdgcn_s_memrealtime();
 #endif
-  flush_sums(P.accum, sums, accpix != 0xffffffffu, accpix, acc_r, acc_g, acc_b, lane);
   sum_cache_drain(P.accum, sums, lane);
   RTOW_PROF_FLUSH();
 #ifdef RTOW_PROFILE_TIMELINE
@@ -899,7 +910,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   }
 #endif
   // ray-segment count: wave reduction, one atomic per wave
-  const unsigned long long total = wave_sum(nseg) + nseg_primary;
+  const unsigned long long total = nseg_bounce + nseg_primary;
   if (lane == 0) atomicAdd(P.seg_counter, total);
 }
 

@@ -1,4 +1,5 @@
-"""Instrumented build (librtow_hip_prof.so): wave-level statistics of the sphere scan."""
+"""Instrumented build (librtow_hip_prof.so, -DRTOW_PROFILE_COUNTERS): wave-level statistics of the two kinds
+of iteration.  usage: prof_counters.py [spp] [C2|C3|C5]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["RTOW_LIB_PATH"] = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "librtow_hip_prof.so")
@@ -8,15 +9,17 @@ L = _lib.lib()
 wl = sys.argv[2] if len(sys.argv) > 2 else 'C2'
 scene = {'C2': lambda: R.randomScene(), 'C3': lambda: R.randomScene(lambertBelow=0.0, metalBelow=0.5), 'C5': lambda: R.randomScene(halfExtent=50)}[wl]()
 r = R.Renderer(0); r.setWorld(scene); r.setCamera(R.bookCamera(1.5))
-buf = (C.c_ulonglong * 16)()
-L.rtow_debug_counters(buf, 1)
+b = (C.c_ulonglong * 16)()
+L.rtow_debug_counters(b, 1)
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 r.renderAsync(1200, 800, spp, 50); r.sync(); st = r.stats()
-L.rtow_debug_counters(buf, 0)
-g, cw, cl, wi, li = buf[0], buf[1], buf[2], buf[3], buf[4]
-print(f"segments {st['ray_segments']}  wave iterations {wi}  lane iterations {li}  lane utilisation {li/(64*wi):.4f}")
-print(f"per wave iteration: group slow-path entries {g/wi:.2f} of {(len(scene)+7)//8*2}, candidate spheres (wave level) {cw/wi:.2f}, candidate lanes {cl/wi:.2f} (per lane {cl/li:.3f})")
-tot = buf[5] + buf[6] + buf[7] + buf[8]
-print(f"wave-cycle split: refill {buf[5]/tot:.3f}  normalise+big {buf[6]/tot:.3f}  scan {buf[7]/tot:.3f}  shade {buf[8]/tot:.3f}  (cycles per wave iteration {tot/wi:.0f})")
-print(f"per wave iteration: groups with a survivor in any lane {buf[9]/wi:.2f}, drain rounds {buf[10]/wi:.2f}, "
-      f"unit-ball loop trips (slowest lane) {buf[11]/wi:.2f}, pool batches {buf[14]/wi:.3f}")
+L.rtow_debug_counters(b, 0)
+it, prim = b[3], b[14]
+bounce = it - prim
+print(f"segments {st['ray_segments']}  paths {st['paths']}  wave iterations {it}: PRIMARY {prim} ({prim/it:.3f}), BOUNCE {bounce}")
+print(f"lanes with a ray: PRIMARY {st['paths']/(64*prim):.4f}, BOUNCE {b[4]/(64*bounce):.4f}, all scans {(st['paths']+b[4])/(64*it):.4f}")
+print(f"cycles per iteration: all {b[15]/it:.0f};  hand-out {b[5]/it:.0f}")
+print(f"  PRIMARY {(b[1]+b[2]+b[13])/prim:.0f} = set-up {b[1]/prim:.0f} + scan {b[2]/prim:.0f} + shading {b[13]/prim:.0f}")
+print(f"  BOUNCE  {(b[6]+b[7]+b[8])/bounce:.0f} = set-up {b[6]/bounce:.0f} + scan {b[7]/bounce:.0f} + shading {b[8]/bounce:.0f}")
+print(f"per iteration: groups with a survivor {b[9]/it:.2f}, exact-test rounds binary32 {b[10]/bounce:.2f} per BOUNCE, binary64 {b[12]/prim:.2f} per PRIMARY, "
+      f"unit-ball trips of the slowest lane {b[11]/bounce:.2f} per BOUNCE")
