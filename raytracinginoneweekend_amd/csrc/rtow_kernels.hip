@@ -78,21 +78,35 @@ typedef float f8v __attribute__((ext_vector_type(8)));
 typedef const f16v __attribute__((address_space(4)))* geom_ptr;
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-// per-ray operands of the packed filter, every component duplicated into both halves of a pair
+// per-ray operands of the packed filter: seven scalars and the threshold in four register pairs.  A packed
+// instruction can take either half of a source pair for both of its lanes (op_sel / op_sel_hi), so no
+// operand has to be stored twice.
 struct ScanRay {
-  f2v ux, uy, uz, nou;     // unit direction, -(o.u)
-  f2v ox2, oy2, oz2;       // 2*o
-  float threshold;         // |o|^2 - margin
+  f2v uxy;     // unit direction x, y
+  f2v uzn;     // unit direction z, -(o.u)
+  f2v oxy;     // 2*o x, y
+  f2v ozt;     // 2*o z, threshold = |o|^2 - margin
 };
 
 static __device__ __forceinline__ ScanRay scan_ray(f3 o, f3 u, float cmax) {
   ScanRay r;
   const FilterRay f = filter_ray(o, u, cmax);
-  r.ux = f2v{u.x, u.x}; r.uy = f2v{u.y, u.y}; r.uz = f2v{u.z, u.z};
-  r.nou = f2v{f.nou, f.nou};
-  r.ox2 = f2v{f.ox2, f.ox2}; r.oy2 = f2v{f.oy2, f.oy2}; r.oz2 = f2v{f.oz2, f.oz2};
-  r.threshold = f.threshold;
+  r.uxy = f2v{u.x, u.y}; r.uzn = f2v{u.z, f.nou};
+  r.oxy = f2v{f.ox2, f.oy2}; r.ozt = f2v{f.oz2, f.threshold};
   return r;
+}
+
+// a * b + c on two spheres at once; a = a pair of sphere coordinates in scalar registers, b = ONE half of
+// the pair `b` (B_HI selects which) used for both spheres, c = an accumulator pair, or one half of `c`
+// for both (C_SEL: 0 = pair as it is, 1 = low half twice, 2 = high half twice)
+template <int B_HI, int C_SEL>
+static __device__ __forceinline__ f2v pk_fma_bcast(f2v a, f2v b, f2v c) {
+  f2v d;
+  if (B_HI == 0 && C_SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+  if (B_HI == 1 && C_SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+  if (B_HI == 0 && C_SEL == 2) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+  static_assert((B_HI == 0 || B_HI == 1) && (C_SEL == 0 || (C_SEL == 2 && B_HI == 0)), "forms the filter uses");
+  return d;
 }
 
 static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
@@ -107,7 +121,7 @@ static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
 // so  disc >= -margin  <=>  n^2 + (2o).c - k >= |o|^2 - margin.   The left side costs eight
 // packed instructions per PAIR of spheres (no per-sphere subtraction of the centre), the right
 // side is one number per ray.  Rounding makes the filter value differ from the exact
-// discriminant by a few ulps of (|o| + |c|)^2, which `margin` (ScanRay::threshold) covers; a sphere
+// discriminant by a few ulps of (|o| + |c|)^2, which `margin` (the threshold in ScanRay::ozt) covers; a sphere
 // that passes is then tested exactly, so the filter only ever adds work, never hits.
 //
 // The table is stored in groups of four spheres, 16 floats per group, as two packed pairs and k:
@@ -118,12 +132,12 @@ static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
 // a separate array, fetched only when needed.
 static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, const f2v cz, const f2v nk,
                                                   const ScanRay& r) {
-  f2v n = __builtin_elementwise_fma(cx, r.ux, r.nou);
-  n = __builtin_elementwise_fma(cy, r.uy, n);
-  n = __builtin_elementwise_fma(cz, r.uz, n);
-  f2v t = __builtin_elementwise_fma(cx, r.ox2, nk);   // nk = -k, a VGPR pair (see K_LDS)
-  t = __builtin_elementwise_fma(cy, r.oy2, t);
-  t = __builtin_elementwise_fma(cz, r.oz2, t);
+  f2v n = pk_fma_bcast<0, 2>(cx, r.uxy, r.uzn);   // cx * u.x - o.u
+  n = pk_fma_bcast<1, 0>(cy, r.uxy, n);
+  n = pk_fma_bcast<0, 0>(cz, r.uzn, n);
+  f2v t = pk_fma_bcast<0, 0>(cx, r.oxy, nk);      // nk = -k, a VGPR pair (see K_LDS)
+  t = pk_fma_bcast<1, 0>(cy, r.oxy, t);
+  t = pk_fma_bcast<0, 0>(cz, r.ozt, t);
   return __builtin_elementwise_fma(n, n, t);
 }
 
@@ -319,13 +333,13 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v 
   const f2v f0 = pair_filter(grp.a.s01, grp.a.s23, grp.a.s45, nk.xy, r);
   const f2v f1 = pair_filter(grp.a.s67, grp.b.xy, grp.b.zw, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
-  if (__ballot(mx >= r.threshold) != 0) {   // wave-uniform: the list's fill count stays a scalar
+  if (__ballot(mx >= r.ozt.y) != 0) {   // wave-uniform: the list's fill count stays a scalar
     RTOW_COUNT(9, 1);
-    RTOW_COUNT(0, mx >= r.threshold ? 1 : 0);
-    cand_push(cand, f0.x >= r.threshold, j);
-    cand_push(cand, f0.y >= r.threshold, j + 1);
-    cand_push(cand, f1.x >= r.threshold, j + 2);
-    cand_push(cand, f1.y >= r.threshold, j + 3);
+    RTOW_COUNT(0, mx >= r.ozt.y ? 1 : 0);
+    cand_push(cand, f0.x >= r.ozt.y, j);
+    cand_push(cand, f0.y >= r.ozt.y, j + 1);
+    cand_push(cand, f1.x >= r.ozt.y, j + 2);
+    cand_push(cand, f1.y >= r.ozt.y, j + 3);
     if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
   }
 }
@@ -349,7 +363,7 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
                                                     float tmin, int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
   ScanRay r = scan_ray(o, u, cmax);
-  if (!live) r.threshold = INFINITY;
+  if (!live) r.ozt.y = INFINITY;
   // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
   // immediate offsets.  (Left to itself the compiler keeps the address in an SGPR and copies it to
   // a VGPR for every read: one more VALU instruction per group.)
