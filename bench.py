@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 FLOP_PER_TEST = 18             # hitrecord.nim:56-61: oc 3, half_b 5, |oc|^2 5, r*r 1, c 1, disc 3
 FLOP_PER_SEGMENT_EXTRA = 65    # a = |dir|^2 once, hit epilogue, scatter, sky (amortised)
+FLOP_PER_TEST_EXECUTED = 14    # what the kernel's screen really issues per sphere: 7 packed FMAs per pair
 
 WORKLOADS = {
     # name: (width, height, spp, depth, half_extent, lambert_below, metal_below)
@@ -44,9 +45,11 @@ def hbm_traffic(workload, spp, world):
     """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled as gfx950 requires, WRITE_SIZE as is); only valid for the configuration it
     was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world != 1 or spp != WORKLOADS[workload][2] or not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))   # the latest round's passes
+    if world != 1 or spp != WORKLOADS[workload][2] or not found:
         return None
+    path = found[-1]
     t = json.load(open(path))
     if t.get("workload") != workload:
         return None
@@ -55,10 +58,14 @@ def hbm_traffic(workload, spp, world):
 
 def cpu_baseline(width, height, depth, seed):
     """Time the FP64 restatement of the reference on a bounded sample: 16 rows spread over the
-    frame.  Single thread first (the reference is single-threaded), then all host cores."""
+    frame.  Single thread first (the reference is single-threaded), then all host cores.  Also the
+    reference's own CPU-sized case in full: 400x225, spp 10, depth 50 (BASELINE config 1), one thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     arr, n, _, _ = O.random_scene()
+    t0 = time.perf_counter()
+    _, _, _, seg_c1 = O.render_ref64(arr, n, O.book_camera(400 / 225), 400, 225, 10, 50, seed=seed, threads=1)
+    t_c1 = time.perf_counter() - t0
     cam = O.book_camera(width / height)
     rows = list(range(height // 32, height, height // 16))[:16]
     spp = 256
@@ -76,6 +83,8 @@ def cpu_baseline(width, height, depth, seed):
                   f"{seg1} segments in {t1:.1f} s",
         "value_all_cores": segm / tm / 1e6, "cores_all": cores,
         "sample_all_cores": f"same rows, spp {2 * spp}, {cores} pthreads, {segm} segments in {tm:.1f} s",
+        "c1_full": {"workload": "C1: 400x225, spp 10, depth 50, 484 spheres, whole frame", "cores": 1,
+                    "seconds": t_c1, "segments": seg_c1, "value": seg_c1 / t_c1 / 1e6, "unit": "Mrays/s"},
     }
 
 
@@ -233,7 +242,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",   # every segment after the first; the primary segment is evaluated in binary64
             "data": "synthetic (the reference's randomScene generator from its fixed default RNG state)",
             "config": {
                 "workload": f"{args.workload}: book-1 random-spheres scene, {width}x{height}, spp {spp}, depth {depth}, "
@@ -260,8 +269,13 @@ def main():
                 "measured_peak_v_fma_f32": 126.8,
                 "measured_peak_v_pk_fma_f32": 147.7,
                 "flop_per_segment": flop_per_segment,
+                # `achieved` counts the reference's work (18 FLOP per ray-sphere test, hitrecord.nim:56-61); the
+                # kernel screens every sphere with 14 FLOP (7 packed FMAs per pair) and runs the full test on
+                # the ~1.2 survivors per ray, so the share of the VALU peak it really issues is lower:
+                "frac_executed_screen_only": serial[-1]["ray_segments"] * FLOP_PER_TEST_EXECUTED * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS,
                 "kernel_ms": avg_trace_s * 1e3,
                 "traffic": hbm_traffic(args.workload, spp, world),
+                "traffic_source": "constant from the committed rocprofv3 PMC passes (profiles/*_traffic.json), not measured in this run",
                 "framebuffer_GBps": (n_rows * width * 3) / (sum(total_ms) / len(total_ms) * 1e-3) / 1e9,
             },
             "cpu_baseline": None,

@@ -165,6 +165,12 @@ static inline double reflectance(double cosine, double ref_idx) {
   return r0 + (1 - r0) * pow(1 - cosine, 5);
 }
 
+/* Negative controls for the tests that pin this file on the reference's own image: a deliberately WRONG
+ * material model must fail those tests.  0 = faithful (the default, and the only value anything but
+ * that one test uses); 1 = no Schlick reflection; 2 = Metal fuzz ignored; 3 = refraction ratio inverted. */
+static atomic_int g_variant;
+void orc_ref64_set_variant(int v) { atomic_store(&g_variant, v); }
+
 /* scatter dispatch (hitrecord.nim:127-132) over the three material procs (:82-125) */
 static int scatter(const orc_sphere* m, ray_t r_in, const hit_record* rec, rng_t* g, v3* attenuation,
                    ray_t* scattered) {
@@ -180,20 +186,21 @@ static int scatter(const orc_sphere* m, ray_t r_in, const hit_record* rec, rng_t
     case ORC_METAL: { /* hitrecord.nim:94-99 */
       const v3 reflected = reflect(unit_vector(r_in.dir), rec->normal);
       scattered->orig = rec->p;
-      scattered->dir = add(reflected, smul(m->fuzz, random_in_unit_sphere(g)));
+      scattered->dir = add(reflected, smul(atomic_load(&g_variant) == 2 ? 0.0 : m->fuzz, random_in_unit_sphere(g)));
       *attenuation = ld(m->albedo);
       return dot(scattered->dir, rec->normal) > 0;
     }
     default: { /* Dielectric, hitrecord.nim:107-125 */
       *attenuation = mk(1.0, 1.0, 1.0);
-      const double refraction_ratio = rec->front_face ? (1.0 / m->ir) : m->ir;
+      const int variant = atomic_load(&g_variant);
+      const double refraction_ratio = (rec->front_face != (variant == 3)) ? (1.0 / m->ir) : m->ir;
       const v3 unit_direction = unit_vector(r_in.dir);
       const double cos_theta = fmin(dot(neg(unit_direction), rec->normal), 1.0);
       const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
       const int cannot_refract = refraction_ratio * sin_theta > 1.0;
       v3 direction;
       /* Nim `or` short-circuits: the draw happens only when refraction is possible */
-      if (cannot_refract || reflectance(cos_theta, refraction_ratio) > rand_max(g, 1.0))
+      if (cannot_refract || (variant != 1 ? reflectance(cos_theta, refraction_ratio) : 0.0) > rand_max(g, 1.0))
         direction = reflect(unit_direction, rec->normal);
       else
         direction = refract(unit_direction, rec->normal, refraction_ratio);

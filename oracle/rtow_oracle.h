@@ -93,6 +93,10 @@ int orc_ref64_render(const orc_sphere* spheres, int n_spheres, const orc_camera*
                      orc_nimrand* nim_state, const int32_t* rows, int n_rows, int n_threads,
                      uint8_t* rgb, double* accum, int32_t* hit_id, uint64_t* ray_segments);
 
+/* Test-only switch to a deliberately wrong material model (negative controls): 0 = faithful (default),
+ * 1 = no Schlick reflection, 2 = Metal fuzz ignored, 3 = refraction ratio inverted.  Process-wide. */
+void orc_ref64_set_variant(int v);
+
 /* FP32 mirror of the GPU arithmetic.  accum_fix: 3 x uint64 per pixel, fixed-point sums with
  * 30 fractional bits (what the kernels accumulate). */
 int orc_mirror32_render(const orc_sphere* spheres, int n_spheres, const orc_camera* cam,

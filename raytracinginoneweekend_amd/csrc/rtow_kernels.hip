@@ -425,12 +425,6 @@ static __device__ __forceinline__ void scan_sparse(ExactPtr exact, const f4v* nk
   cand_drain<false>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
 
-static __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 // A path that ends with light (the sky) adds its fixed-point radiance to its pixel.  The paths of a wave
 // belong to a handful of pixels at a time (a chunk is a run of consecutive samples), so the sums are
 // collected in a small per-wave cache in LDS first - four direct-mapped slots of three 64-bit words,

@@ -69,6 +69,18 @@ if os.path.exists(png):
         "row_profile_g_box8": [im[y, :, 1].reshape(150, 8).mean(1).round(2).tolist() for y in rows],
     }, open(os.path.join(HERE, "reference_png_stats.json"), "w"), indent=1)
 
+    # 8 x 8 box means of the whole image (150 x 100 boxes): each mean is a multiple of 1/64, stored x 64
+    thumb = im.astype(np.uint32).reshape(100, 8, 150, 8, 3).sum((1, 3)).astype(np.uint16)
+    # which boxes lie (>= 95 % of their pixels) on which object, from the oracle's primary hit ids: the three big
+    # spheres of raytracer.nim:104-111, the small spheres by material, the ground, the sky
+    _, _, hid, _ = O.render_ref64(arr, n, O.book_camera(1.5), 1200, 800, 1, 1)
+    ids = hid.reshape(100, 8, 150, 8)
+    small = lambda kind: [j for j in range(1, n - 3) if arr[j].kind == kind]  # noqa: E731
+    sets = {"glass": [n - 3], "brown": [n - 2], "bigmetal": [n - 1], "smalllambert": small(0), "smallmetal": small(1),
+            "smallglass": small(2), "ground": [0], "sky": [-1]}
+    masks = {"mask_" + k: np.packbits(np.isin(ids, v).mean((1, 3)) >= 0.95) for k, v in sets.items()}
+    np.savez_compressed(os.path.join(HERE, "reference_png_thumb.npz"), thumb_x64=thumb, **masks)
+
 # ---- FP32 mirror fixtures the GPU must reproduce bit for bit
 cam = O.book_camera(64 / 48)
 rgb, acc, hid, seg = O.render_mirror32(arr, n, cam, 64, 48, 1, 1)

@@ -92,6 +92,8 @@ def lib():
     L.orc_ref64_get_ray.argtypes = [C.POINTER(Camera), C.c_double, C.c_double, u32p, u32p, dp, dp]
     L.orc_ref64_get_ray.restype = None
     L.orc_ref64_quantise.argtypes = [C.c_double, C.c_int]
+    L.orc_ref64_set_variant.argtypes = [C.c_int]
+    L.orc_ref64_set_variant.restype = None
     _lib = L
     return L
 

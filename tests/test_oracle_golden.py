@@ -99,6 +99,57 @@ def test_rows_agree_with_reference_png_statistics(oracle, book_scene):
         assert np.corrcoef(prof_ref, prof_orc)[0, 1] > 0.97, y
 
 
+def test_materials_pinned_by_reference_png_thumbnail(oracle, book_scene):
+    """The FP64 restatement against 8 x 8 box means of the reference's own 500-spp render, over a third of the
+    frame's 8-row bands at spp 16, separately for the boxes on the big glass, brown and metal spheres, on small
+    spheres of each material, on the ground and on the sky.  Then the negative controls: the same renderer with
+    Schlick's reflection removed, with Metal's fuzz ignored, and with the refraction ratio inverted must each
+    FAIL the limit of the object they change - so the limits do pin Schlick, fuzz and refraction."""
+    from conftest import PNG_LIMITS_SPP16, load_png_thumbnail, png_box_differences
+    arr, n = book_scene
+    thumb, masks = load_png_thumbnail()
+    cam = oracle.book_camera(1.5)
+    bands = list(range(2, 96, 3))
+    rows = [8 * b + k for b in bands for k in range(8)]
+    assert min(masks[k][bands].sum() for k in PNG_LIMITS_SPP16 if k != "all") >= 60   # every object is well covered
+
+    def differences(variant):
+        oracle.lib().orc_ref64_set_variant(variant)
+        try:
+            rgb = oracle.render_ref64(arr, n, cam, 1200, 800, 16, 50, rows=rows, threads=16)[0]
+        finally:
+            oracle.lib().orc_ref64_set_variant(0)
+        return png_box_differences(rgb, thumb, masks, bands)
+
+    d = differences(0)
+    for k, limit in PNG_LIMITS_SPP16.items():
+        assert d[k] <= limit, (k, d[k], limit)
+    assert d["bias"] <= 0.5, d["bias"]            # mean RGB of the bands within half a level of the reference's
+    no_schlick, no_fuzz, inverted = differences(1), differences(2), differences(3)
+    assert no_schlick["glass"] > 3 * PNG_LIMITS_SPP16["glass"] and no_schlick["smallglass"] > 2 * PNG_LIMITS_SPP16["smallglass"]
+    assert no_fuzz["smallmetal"] > 1.8 * PNG_LIMITS_SPP16["smallmetal"]
+    assert inverted["glass"] > 20 * PNG_LIMITS_SPP16["glass"]
+    # what the controls do not touch stays within its limit
+    assert no_fuzz["glass"] <= PNG_LIMITS_SPP16["glass"] and no_schlick["smallmetal"] <= PNG_LIMITS_SPP16["smallmetal"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/media/rayTracing.png"),
+                    reason="reference image only exists in the build container")
+def test_png_thumbnail_fixture_matches_reference_image(oracle, book_scene):
+    from PIL import Image
+    from conftest import load_png_thumbnail
+    im = np.asarray(Image.open("/root/reference/media/rayTracing.png").convert("RGB")).astype(np.float64)
+    thumb, masks = load_png_thumbnail()
+    assert (thumb == im.reshape(100, 8, 150, 8, 3).mean((1, 3))).all()
+    assert np.allclose(thumb.mean((0, 1)), [131.87439, 140.90676, 157.15436], atol=1e-4)
+    arr, n = book_scene
+    hid = oracle.render_ref64(arr, n, oracle.book_camera(1.5), 1200, 800, 1, 1, threads=16)[2]
+    ids = hid.reshape(100, 8, 150, 8)
+    assert (masks["glass"] == ((ids == n - 3).mean((1, 3)) >= 0.95)).all()
+    assert (masks["sky"] == ((ids == -1).mean((1, 3)) >= 0.95)).all()
+    assert sum(int(m.sum()) for m in masks.values()) > 12000   # most of the 15 000 boxes lie on one object
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/media/rayTracing.png"),
                     reason="reference image only exists in the build container")
 def test_png_stats_fixture_matches_reference_image():
