@@ -1,38 +1,51 @@
-## Drop-in body for `render*` of raytracer.nim: same signature, the triple loop replaced by one
-## call.  `flatten` must live in camera.nim / hittables.nim because Camera's fields are private.
-import strformat
+## Drop-in bodies for the procs of the hot path, same names and parameter lists as the reference:
+##   render*    raytracer.nim:30-32   (the triple loop replaced by one call; `seed` added, defaulted)
+##   rayColor*  raytracer.nim:5       hit*  hittables.nim:79       getRay*  camera.nim:34
+## `flatten` (Camera -> RtowCameraF64) must live in camera.nim because Camera's fields are private
+## (camera.nim:5-10); see INTEGRATION.md.  Import this module INSTEAD of the reference's own definitions
+## of these four procs.  Unverified in the build image (no Nim toolchain there).
 import basetypes, hittables, camera, hitrecord, rtow_abi
 
 proc check(status: cint, what: string) =
   if status != 0: raise newException(IOError, what & ": " & $rtow_last_error())
 
-proc renderGpu*(img: Image, f: string, world: var HittablesList, camera: Camera,
-                samplesPerPixel, maxDepth: int, seed: uint64 = 0xE7) =
-  var cx, cy, cz, rad, albedo, fuzz, ir: seq[cfloat]
-  var kind: seq[uint8]
-  for obj in world:                       # list order is kept: it decides ties
+type Flat = object
+  cx, cy, cz, rad, albedo, fuzz, ir: seq[cdouble]
+  kind: seq[uint8]
+
+proc flatten(world: var HittablesList): Flat =
+  for obj in world:                       # list order is kept: it decides ties (hittables.nim:84-88)
     let s = obj.hSphere
-    cx.add s.center.x.cfloat; cy.add s.center.y.cfloat; cz.add s.center.z.cfloat
-    rad.add s.radius.cfloat
-    kind.add s.mat.kind.ord.uint8
+    result.cx.add s.center.x; result.cy.add s.center.y; result.cz.add s.center.z
+    result.rad.add s.radius
+    result.kind.add s.mat.kind.ord.uint8
     case s.mat.kind
     of mkLambertian:
-      for i in 0 ..< 3: albedo.add s.mat.mLambertian.albedo[i].cfloat
-      fuzz.add 0; ir.add 1
+      for i in 0 ..< 3: result.albedo.add s.mat.mLambertian.albedo[i]
+      result.fuzz.add 0; result.ir.add 1
     of mkMetal:
-      for i in 0 ..< 3: albedo.add s.mat.mMetal.albedo[i].cfloat
-      fuzz.add s.mat.mMetal.fuzz.cfloat; ir.add 1
+      for i in 0 ..< 3: result.albedo.add s.mat.mMetal.albedo[i]
+      result.fuzz.add s.mat.mMetal.fuzz; result.ir.add 1
     of mkDielectric:
-      for i in 0 ..< 3: albedo.add 1
-      fuzz.add 0; ir.add s.mat.mDielectric.ir.cfloat
+      for i in 0 ..< 3: result.albedo.add 1
+      result.fuzz.add 0; result.ir.add s.mat.mDielectric.ir
+
+template p(s: seq[cdouble]): ptr cdouble = (if s.len > 0: unsafeAddr s[0] else: nil)
+
+proc upload(ctx: RtowCtx, world: var HittablesList) =
+  let f = flatten(world)
+  let kinds = if f.kind.len > 0: unsafeAddr f.kind[0] else: nil   # an empty world is legal: every ray sees the sky
+  check rtow_set_scene_f64(ctx, f.rad.len.cint, p(f.cx), p(f.cy), p(f.cz), p(f.rad), kinds, p(f.albedo), p(f.fuzz), p(f.ir)),
+        "rtow_set_scene_f64"
+
+proc render*(img: Image, f: string, world: var HittablesList, camera: Camera,
+             samplesPerPixel, maxDepth: int, seed: uint64 = 0xE7) =
   var ctx: RtowCtx
   check rtow_create(0, addr ctx), "rtow_create"
   defer: discard rtow_destroy(ctx)
-  let n = rad.len.cint
-  check rtow_set_scene(ctx, n, addr cx[0], addr cy[0], addr cz[0], addr rad[0], addr kind[0],
-                       addr albedo[0], addr fuzz[0], addr ir[0]), "rtow_set_scene"
-  var cam = camera.flatten()              # proc flatten*(c: Camera): RtowCamera, added to camera.nim
-  check rtow_set_camera(ctx, addr cam), "rtow_set_camera"
+  upload(ctx, world)
+  var cam = camera.flatten()              # proc flatten*(c: Camera): RtowCameraF64, added to camera.nim
+  check rtow_set_camera_f64(ctx, addr cam), "rtow_set_camera_f64"
   # the image stays in the context; the P3 text of raytracer.nim:28,35 is composed on the device
   check rtow_render(ctx, img.width.cint, img.height.cint, samplesPerPixel.cint, maxDepth.cint, seed,
                     nil, img.height.cint, nil, nil, nil), "rtow_render"
@@ -41,3 +54,51 @@ proc renderGpu*(img: Image, f: string, world: var HittablesList, camera: Camera,
   var text = newString(length.int)
   check rtow_format_ppm(ctx, 0, text.cstring, length, addr length), "rtow_format_ppm"
   writeFile(f, text)
+
+# ---- per-ray procs: a context is kept per thread, the world / camera are uploaded again when they change
+var gCtx {.threadvar.}: RtowCtx
+var gWorldLen {.threadvar.}: int
+var gWorldData {.threadvar.}: pointer
+
+proc device(): RtowCtx =
+  if gCtx.pointer == nil: check rtow_create(0, addr gCtx), "rtow_create"
+  gCtx
+
+proc deviceWith(world: var HittablesList): RtowCtx =
+  result = device()
+  if gWorldData != cast[pointer](addr world) or gWorldLen != world.len:
+    upload(result, world)
+    gWorldData = cast[pointer](addr world); gWorldLen = world.len
+
+proc rayColor*(r: Ray, world: var HittablesList, depth: int): Color =
+  let ctx = deviceWith(world)
+  var o = [r.orig.x, r.orig.y, r.orig.z]
+  var d = [r.dir.x, r.dir.y, r.dir.z]
+  var c: array[3, cdouble]
+  check rtow_trace_rays(ctx, 1, addr o[0], addr d[0], 0.001, Inf, depth.cint, 0xE7'u64, addr c[0], nil, nil), "rtow_trace_rays"
+  color(c[0], c[1], c[2])
+
+proc hit*(h: var HittablesList, r: Ray, t_min, t_max: float, rec: var HitRecord): bool =
+  let ctx = deviceWith(h)
+  var o = [r.orig.x, r.orig.y, r.orig.z]
+  var d = [r.dir.x, r.dir.y, r.dir.z]
+  var id: int32
+  var t: cdouble
+  check rtow_trace_rays(ctx, 1, addr o[0], addr d[0], t_min, t_max, 0, 0xE7'u64, nil, addr id, addr t), "rtow_trace_rays"
+  if id < 0: return false
+  let s = h[id.int].hSphere
+  rec.t = t
+  rec.p = r.at(rec.t)
+  rec.setFaceNormal(r, (rec.p - s.center) / s.radius)      # hitrecord.nim:73-77
+  rec.mat = s.mat
+  true
+
+proc getRay*(c: Camera, s, t: float): Ray =
+  let ctx = device()
+  var cam = c.flatten()
+  check rtow_set_camera_f64(ctx, addr cam), "rtow_set_camera_f64"
+  var ss = s.cdouble
+  var tt = t.cdouble
+  var o, d: array[3, cdouble]
+  check rtow_get_rays(ctx, 1, addr ss, addr tt, 0xE7'u64, addr o[0], addr d[0]), "rtow_get_rays"
+  initRay(point(o[0], o[1], o[2]), vec3(d[0], d[1], d[2]))

@@ -178,6 +178,30 @@ int rtow_render_noalloc(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uin
  * bytes, accum_out n_rows*w*3 uint64 fixed-point sums; either may be NULL. */
 int rtow_read_image(rtow_ctx* ctx, uint8_t* rgb_out, uint64_t* accum_out);
 
+/* The reference's per-ray procs, batched: for n caller-given rays (binary64, n*3 origins and n*3
+ * directions, directions not normalised - camera.nim:38-39 does not normalise either)
+ *   hit_id_out[i], t_out[i]   hit*(world, r, t_min, t_max, rec) (hittables.nim:79-88 over Sphere.hit,
+ *                             hitrecord.nim:55-79): list index of the closest hit in [t_min, t_max]
+ *                             and its t in units of |direction| (-1 and +inf for a miss); the rest of
+ *                             the HitRecord follows from them on the host (p = orig + t*dir, ...);
+ *   color_out[3*i..]          rayColor*(r, world, max_depth) (raytracer.nim:5-20), un-scaled radiance.
+ * The arithmetic is the renderer's: this query in binary64 with the reference's operations, any further
+ * bounce in binary32; ray i scatters with the random stream of path (pixel i, sample 0) of `seed`.
+ * rayColor itself uses t_min = 0.001 and t_max = +inf (raytracer.nim:11); other values give the colour
+ * of a ray whose FIRST query is restricted to [t_min, t_max].  max_depth = 0 answers the hit query
+ * only (colours are 0, as rayColor returns at depth <= 0).  Any output may be NULL.  Host pointers;
+ * blocks until the results are there.  Needs rtow_set_scene; n at most 2^27. */
+int rtow_trace_rays(rtow_ctx* ctx, int n, const double* origins, const double* directions, double t_min,
+                    double t_max, int max_depth, uint64_t seed, double* color_out, int32_t* hit_id_out,
+                    double* t_out);
+
+/* getRay*(c, s, t) (camera.nim:34-39) for n (s, t) pairs in binary64: origins_out and directions_out
+ * (n*3 each) of the thin-lens rays.  Ray i takes its lens sample (randomInUnitDisk, basetypes.nim:130-134)
+ * from the first draws of the stream of path (pixel i, sample 0) of `seed`, where the reference draws
+ * from its one global stream.  Needs rtow_set_camera. */
+int rtow_get_rays(rtow_ctx* ctx, int n, const double* s, const double* t, uint64_t seed,
+                  double* origins_out, double* directions_out);
+
 /* One frame on several contexts at once - normally one context per GPU of this process, each
  * holding the same scene and camera.  The rows of the image - the outer j loop of render
  * (raytracer.nim:36) - are dealt to the contexts in interleaved tiles of tile_rows rows (tile t goes

@@ -231,9 +231,8 @@ static int closest_hit(const sph32* w, int n, float cmax, f3 o, f3 u, float tmin
  * binary64, in list order with the shrinking t_max, for the spheres the binary32 screen lets through
  * (o, u: binary32 roundings of the ray, u normalised in binary32) and for the |radius| >= 100 ones. */
 static int primary_hit(const sph32* w, int n, float cmax, const double o64[3], const double d64[3], f3 o, f3 u,
-                       double* t_out) {
-  const double t_min = 0.001; /* raytracer.nim:11 */
-  double closest = INFINITY;
+                       double t_min, double t_max, double* t_out) {
+  double closest = t_max;
   int id = -1;
   const float nou = -dot3(o, u);
   const float ox2 = 2.0f * o.x, oy2 = 2.0f * o.y, oz2 = 2.0f * o.z;
@@ -288,37 +287,24 @@ static inline uint64_t to_fix(float c) {
   return (uint64_t)(uint32_t)(c * FIX_ONE);
 }
 
-/* one path: returns radiance in fixed point, counts world.hit queries */
-static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t sample, uint64_t fix[3],
-                       int* first_id, uint64_t* segments, int32_t* trail, int trail_cap, int* trail_len) {
-  const cam32* cam = jb->cam;
-  stream g;
-  orc_path_key(jb->seed, pixel, sample, g.key);
-  g.k = 0;
-  /* ---- primary segment in binary64: raytracer.nim:41-42 (u before v), camera.nim:34-39 with
-   * basetypes.nim:130-134; every draw is a 24-bit value, exactly representable in both widths */
-  const orc_camera* c64 = cam->c64;
-  const double xi1 = (double)draw(&g), xi2 = (double)draw(&g);
-  const double su = ((double)i + xi1) / (double)(jb->W - 1);
-  const double sv = ((double)j + xi2) / (double)(jb->H - 1);
-  double lx, ly;
-  do { lx = (double)draw(&g) * 2.0 + -1.0; ly = (double)draw(&g) * 2.0 + -1.0; } while (lx * lx + ly * ly >= 1.0);
-  const double rdx = c64->lens_radius * lx, rdy = c64->lens_radius * ly;
-  double o64[3], d64[3];
-  for (int k = 0; k < 3; ++k) {
-    const double off = c64->u[k] * rdx + c64->v[k] * rdy;
-    o64[k] = c64->origin[k] + off;
-    d64[k] = c64->lower_left[k] + su * c64->horizontal[k] + sv * c64->vertical[k] - c64->origin[k] - off;
-  }
+/* rayColor (raytracer.nim:5-20) for one ray given in binary64: the first world.hit in binary64 over
+ * [t_min, t_max], every later segment in binary32.  colour: binary64 sky colour for a first-segment miss,
+ * otherwise the binary32 radiance of the path (widened); returns 1 when the colour is such a binary64 sky
+ * sample.  Counts world.hit queries. */
+static int trace_ray(const job32* jb, const double o64[3], const double d64[3], double t_min, double t_max, stream* gp,
+                     int max_depth, double colour[3], int* first_id, double* first_t, uint64_t* segments, int32_t* trail,
+                     int trail_cap, int* trail_len) {
+  stream g = *gp;
   f3 o = {(float)o64[0], (float)o64[1], (float)o64[2]};
   f3 d = {(float)d64[0], (float)d64[1], (float)d64[2]};
 
   float tr = 1.0f, tg = 1.0f, tb = 1.0f; /* throughput */
   float rr = 0.0f, rg = 0.0f, rb = 0.0f; /* radiance of the path */
   *first_id = -1;
+  if (first_t) *first_t = INFINITY;
   int prev = -1; /* sphere the ray starts on */
-  fix[0] = fix[1] = fix[2] = 0;
-  for (int depth = jb->max_depth; depth > 0; --depth) { /* depth <= 0 -> black (raytracer.nim:8-9) */
+  colour[0] = colour[1] = colour[2] = 0.0;
+  for (int depth = max_depth; depth > 0; --depth) { /* depth <= 0 -> black (raytracer.nim:8-9) */
     ++*segments;
     const float len = sqrtf(dot3(d, d));
     const float il = 1.0f / len;
@@ -327,19 +313,21 @@ static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t s
     float t = 0.0f;
     int id;
     f3 p;
-    if (depth == jb->max_depth) {
+    if (depth == max_depth) {
       double t64;
-      id = primary_hit(jb->w, jb->n, jb->cmax, o64, d64, o, u, &t64);
+      id = primary_hit(jb->w, jb->n, jb->cmax, o64, d64, o, u, t_min, t_max, &t64);
       *first_id = id;
+      if (first_t && id >= 0) *first_t = t64;
       if (trail) { if (*trail_len < trail_cap) trail[*trail_len] = id; ++*trail_len; }
       if (id < 0) { /* sky, raytracer.nim:18-20, in binary64; the throughput is 1 */
         const double a = d64[0] * d64[0] + d64[1] * d64[1] + d64[2] * d64[2];
         const double uy = d64[1] / sqrt(a);
         const double ts = 0.5 * (uy + 1.0);
-        fix[0] = to_fix64((1.0 - ts) * 1.0 + ts * 0.5);
-        fix[1] = to_fix64((1.0 - ts) * 1.0 + ts * 0.7);
-        fix[2] = to_fix64((1.0 - ts) * 1.0 + ts * 1.0);
-        return;
+        colour[0] = (1.0 - ts) * 1.0 + ts * 0.5;
+        colour[1] = (1.0 - ts) * 1.0 + ts * 0.7;
+        colour[2] = (1.0 - ts) * 1.0 + ts * 1.0;
+        *gp = g;
+        return 1;
       }
       p.x = (float)(o64[0] + t64 * d64[0]); p.y = (float)(o64[1] + t64 * d64[1]); p.z = (float)(o64[2] + t64 * d64[2]);
     } else {
@@ -404,7 +392,36 @@ static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t s
     d = nd;
     prev = id;
   }
-  fix[0] = to_fix(rr); fix[1] = to_fix(rg); fix[2] = to_fix(rb);
+  colour[0] = rr; colour[1] = rg; colour[2] = rb;
+  *gp = g;
+  return 0;
+}
+
+/* one path of the render: camera ray in binary64 (raytracer.nim:41-42 u before v, camera.nim:34-39 with
+ * basetypes.nim:130-134; every draw is a 24-bit value, exactly representable in both widths), then
+ * rayColor; returns radiance in fixed point */
+static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t sample, uint64_t fix[3],
+                       int* first_id, uint64_t* segments, int32_t* trail, int trail_cap, int* trail_len) {
+  const orc_camera* c64 = jb->cam->c64;
+  stream g;
+  orc_path_key(jb->seed, pixel, sample, g.key);
+  g.k = 0;
+  const double xi1 = (double)draw(&g), xi2 = (double)draw(&g);
+  const double su = ((double)i + xi1) / (double)(jb->W - 1);
+  const double sv = ((double)j + xi2) / (double)(jb->H - 1);
+  double lx, ly;
+  do { lx = (double)draw(&g) * 2.0 + -1.0; ly = (double)draw(&g) * 2.0 + -1.0; } while (lx * lx + ly * ly >= 1.0);
+  const double rdx = c64->lens_radius * lx, rdy = c64->lens_radius * ly;
+  double o64[3], d64[3];
+  for (int k = 0; k < 3; ++k) {
+    const double off = c64->u[k] * rdx + c64->v[k] * rdy;
+    o64[k] = c64->origin[k] + off;
+    d64[k] = c64->lower_left[k] + su * c64->horizontal[k] + sv * c64->vertical[k] - c64->origin[k] - off;
+  }
+  double colour[3];
+  const int sky64 = trace_ray(jb, o64, d64, 0.001, INFINITY, &g, jb->max_depth, colour, first_id, NULL, segments, trail,
+                              trail_cap, trail_len);
+  for (int k = 0; k < 3; ++k) fix[k] = sky64 ? to_fix64(colour[k]) : to_fix((float)colour[k]);
 }
 
 static int quantise_fix(uint64_t sum, int spp) {
@@ -492,4 +509,36 @@ int orc_mirror32_trace_path(const orc_sphere* spheres, int n_spheres, const orc_
   if (fix) { fix[0] = f[0]; fix[1] = f[1]; fix[2] = f[2]; }
   free(w);
   return len;
+}
+
+/* rayColor / hit of one caller-given ray with the renderer's arithmetic (what rtow_trace_rays computes):
+ * returns the list index hit first in [t_min, t_max] (-1: none), its t, and the colour; the random stream
+ * is that of path (pixel = index, sample 0), from its first draw */
+int orc_mirror32_trace_ray(const orc_sphere* spheres, int n_spheres, const double orig[3], const double dir[3],
+                           double t_min, double t_max, int max_depth, uint64_t seed, uint32_t index, double colour[3],
+                           double* t) {
+  sph32* w = (sph32*)malloc(sizeof(sph32) * (size_t)(n_spheres > 0 ? n_spheres : 1));
+  float cmax;
+  prep_scene(spheres, n_spheres, w, &cmax);
+  job32 jb = {w, n_spheres, cmax, NULL, 2, 2, 1, max_depth, seed, NULL, 0, NULL, NULL, NULL, NULL, 0};
+  stream g;
+  orc_path_key(seed, index, 0u, g.key);
+  g.k = 0;
+  int first = -1, len = 0;
+  uint64_t seg = 0;
+  double c[3] = {0, 0, 0}, t64 = INFINITY;
+  if (max_depth > 0) {
+    (void)trace_ray(&jb, orig, dir, t_min, t_max, &g, max_depth, c, &first, &t64, &seg, NULL, 0, &len);
+  } else { /* the hit query alone */
+    f3 o = {(float)orig[0], (float)orig[1], (float)orig[2]};
+    f3 d = {(float)dir[0], (float)dir[1], (float)dir[2]};
+    const float il = 1.0f / sqrtf(dot3(d, d));
+    const f3 u = {d.x * il, d.y * il, d.z * il};
+    first = primary_hit(w, n_spheres, cmax, orig, dir, o, u, t_min, t_max, &t64);
+    if (first < 0) t64 = INFINITY;
+  }
+  if (colour) { colour[0] = c[0]; colour[1] = c[1]; colour[2] = c[2]; }
+  if (t) *t = t64;
+  free(w);
+  return first;
 }

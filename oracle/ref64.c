@@ -494,3 +494,14 @@ int orc_ref64_trace_path(const orc_sphere* spheres, int n_spheres, const orc_cam
   if (colour) st(colour, c);
   return cx.trail_len;
 }
+
+/* rayColor (raytracer.nim:5-20) of one caller-given ray, counter stream of path (pixel = index, sample 0) */
+void orc_ref64_ray_color(const orc_sphere* spheres, int n, const double orig[3], const double dir[3], int depth,
+                         uint64_t seed, uint32_t index, double colour[3]) {
+  trace_ctx cx = {spheres, n, 0, NULL, 0, 0};
+  rng_t g;
+  g.mode = ORC_RNG_COUNTER; g.nim = NULL; g.k = 0;
+  orc_path_key(seed, index, 0u, g.key);
+  const ray_t r = {ld(orig), ld(dir)};
+  st(colour, ray_color(&cx, r, depth, &g, NULL));
+}

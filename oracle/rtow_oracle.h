@@ -137,6 +137,15 @@ int orc_ref64_scatter(const orc_sphere* s, const double in_orig[3], const double
 /* getRay (camera.nim:34-39) */
 void orc_ref64_get_ray(const orc_camera* cam, double s, double t, const uint32_t key[2], uint32_t* k,
                        double orig[3], double dir[3]);
+/* rayColor (raytracer.nim:5-20) of one caller-given ray; scattering draws from the counter stream of path
+ * (pixel = index, sample 0) */
+void orc_ref64_ray_color(const orc_sphere* spheres, int n, const double orig[3], const double dir[3], int depth,
+                         uint64_t seed, uint32_t index, double colour[3]);
+/* the same ray with the renderer's arithmetic (first query in binary64 over [t_min, t_max], later segments in
+ * binary32): what rtow_trace_rays must return bit for bit.  Returns the list index hit first, -1 for none. */
+int orc_mirror32_trace_ray(const orc_sphere* spheres, int n_spheres, const double orig[3], const double dir[3],
+                           double t_min, double t_max, int max_depth, uint64_t seed, uint32_t index, double colour[3],
+                           double* t);
 /* writeColor quantisation of one channel sum (raytracer.nim:22-28) */
 int orc_ref64_quantise(double channel_sum, int spp);
 

@@ -48,3 +48,9 @@ def initCamera(lookFrom, lookAt, vup, vfov, aspectRatio, aperture=0.0, focusDist
                          - focusDist * Point(*c.w))
     c.lensRadius = aperture / 2.0
     return c
+
+
+def getRay(c, s, t, **kw):
+    """getRay*(c: Camera, s, t: float): Ray (camera.nim:34-39), evaluated on the GPU (raytracer.getRay)."""
+    from . import raytracer
+    return raytracer.getRay(c, s, t, **kw)

@@ -89,6 +89,7 @@ struct rtow_ctx {
   uint64_t ppm_bytes = 0;                     // length of that text, 0 = not composed yet
   bool image_in_workspace = false;            // the last render left its 8-bit image in `rgb`
   bool sums_in_workspace = false;             // ... and its radiance sums in `accum`
+  DevBuf ray_in, ray_out;                     // staging of rtow_trace_rays / rtow_get_rays
   DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
   unsigned char* scratch_dev = nullptr;       // this GPU's copy of the no-allocation work memory
   uint64_t* host_counters = nullptr;          // pinned, 16 bytes
@@ -185,7 +186,7 @@ int rtow_destroy(rtow_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
-  c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release();
+  c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release(); c->ray_in.release(); c->ray_out.release();
   if (c->host_counters) (void)hipHostFree(c->host_counters);
   for (int k = 0; k < 2; ++k) {
     if (c->staging[k]) (void)hipHostFree(c->staging[k]);
@@ -698,6 +699,63 @@ int rtow_format_ppm(rtow_ctx* c, int binary, char* out, uint64_t capacity, uint6
   memcpy(out, header, (size_t)header_len);
   if (body) return copy_to_host(c, out + header_len, binary ? c->rgb.p : c->ppm_text.p, (size_t)body);
   return RTOW_OK;
+}
+
+// shared body of rtow_trace_rays and rtow_get_rays: in_a / in_b are n*stride doubles each
+static int run_rays(rtow_ctx* c, const char* who, bool get_rays, int n, const double* in_a, const double* in_b, int stride,
+                    double t_min, double t_max, int max_depth, uint64_t seed, double* out3_a, int32_t* out_id,
+                    double* out_b, int out_b_stride) {
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->pending) { const int rc = rtow_sync(c); if (rc != RTOW_OK) return rc; }
+  if (n == 0) return RTOW_OK;
+  const size_t in_bytes = sizeof(double) * (size_t)n * (size_t)stride;
+  const size_t a_bytes = sizeof(double) * 3 * (size_t)n, id_bytes = sizeof(int32_t) * (size_t)n;
+  const size_t b_bytes = sizeof(double) * (size_t)out_b_stride * (size_t)n;
+  HIP_TRY(c->ray_in.reserve(2 * in_bytes));
+  HIP_TRY(c->ray_out.reserve(a_bytes + b_bytes + id_bytes));
+  HIP_TRY(hipMemcpyAsync(c->ray_in.p, in_a, in_bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync((char*)c->ray_in.p + in_bytes, in_b, in_bytes, hipMemcpyHostToDevice, c->stream));
+  rtow::RayParams p;
+  p.cam = c->cam;
+  p.orig = (const double*)c->ray_in.p; p.dir = (const double*)((char*)c->ray_in.p + in_bytes);
+  p.n = n; p.t_min = t_min; p.t_max = t_max; p.max_depth = max_depth;
+  p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+  p.geom_nk = (const float*)c->geom_nk.p; p.geom_exact = (const float4*)c->geom_rr.p; p.geom64 = (const double4*)c->geom64.p;
+  p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
+  p.shade = (const rtow::SphereShade*)c->shade.p; p.n_list = c->n_spheres; p.cmax = c->cmax;
+  p.color = (get_rays || out3_a) ? (double*)c->ray_out.p : nullptr;
+  p.t = (get_rays || out_b) ? (double*)((char*)c->ray_out.p + a_bytes) : nullptr;
+  p.hit_id = out_id ? (int32_t*)((char*)c->ray_out.p + a_bytes + b_bytes) : nullptr;
+  rtow::launch_rays(p, get_rays, c->stream);
+  HIP_TRY(hipGetLastError());
+  if (out3_a) HIP_TRY(hipMemcpyAsync(out3_a, p.color, a_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (out_b) HIP_TRY(hipMemcpyAsync(out_b, p.t, b_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (out_id) HIP_TRY(hipMemcpyAsync(out_id, p.hit_id, id_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  (void)who;
+  return RTOW_OK;
+}
+
+int rtow_trace_rays(rtow_ctx* c, int n, const double* origins, const double* directions, double t_min, double t_max,
+                    int max_depth, uint64_t seed, double* color_out, int32_t* hit_id_out, double* t_out) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_trace_rays: ctx is NULL");
+  if (!c->have_scene) return fail(RTOW_ERR_STATE, "rtow_trace_rays: call rtow_set_scene first");
+  if (n < 0 || (n > 0 && (!origins || !directions))) return fail(RTOW_ERR_INVALID, "rtow_trace_rays: n = %d or NULL rays", n);
+  if (n > (1 << 27)) return fail(RTOW_ERR_INVALID, "rtow_trace_rays: n = %d rays in one call (at most 2^27)", n);
+  if (!(t_min <= t_max)) return fail(RTOW_ERR_INVALID, "rtow_trace_rays: t_min = %g, t_max = %g", t_min, t_max);
+  if (max_depth < 0) return fail(RTOW_ERR_INVALID, "rtow_trace_rays: max_depth = %d", max_depth);
+  return run_rays(c, "rtow_trace_rays", false, n, origins, directions, 3, t_min, t_max, max_depth, seed, color_out, hit_id_out,
+                  t_out, 1);
+}
+
+int rtow_get_rays(rtow_ctx* c, int n, const double* s, const double* t, uint64_t seed, double* origins_out,
+                  double* directions_out) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_get_rays: ctx is NULL");
+  if (!c->have_camera) return fail(RTOW_ERR_STATE, "rtow_get_rays: call rtow_set_camera first");
+  if (n < 0 || (n > 0 && (!s || !t || !origins_out || !directions_out)))
+    return fail(RTOW_ERR_INVALID, "rtow_get_rays: n = %d or NULL array", n);
+  if (n > (1 << 27)) return fail(RTOW_ERR_INVALID, "rtow_get_rays: n = %d rays in one call (at most 2^27)", n);
+  return run_rays(c, "rtow_get_rays", true, n, s, t, 1, 0.0, 0.0, 0, seed, origins_out, nullptr, directions_out, 3);
 }
 
 int rtow_selftest_arithmetic(rtow_ctx* c, uint64_t mismatches[2]) {

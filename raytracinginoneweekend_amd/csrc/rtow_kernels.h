@@ -43,6 +43,26 @@ struct TraceParams {
   unsigned long long* seg_counter;  // zeroed before launch
 };
 
+// rayColor / hit for n caller-given rays, or getRay for n (s, t) pairs: one lane per ray
+struct RayParams {
+  CameraParams64 cam;
+  const double* orig;        // n*3 ray origins          (getRay: n values of s)
+  const double* dir;         // n*3 ray directions       (getRay: n values of t)
+  int n;
+  double t_min, t_max;       // interval of the first hit query (hittables.nim:79)
+  int max_depth;             // rayColor's depth; <= 0: hit query only
+  uint32_t seed_lo, seed_hi;
+  const float* geom_nk; const float4* geom_exact; const double4* geom64;
+  const BigSphere* big; int n_big;
+  const SphereShade* shade;
+  int n_list;
+  float cmax;
+  double* color;             // n*3 or nullptr           (getRay: n*3 origins out)
+  int32_t* hit_id;           // n or nullptr
+  double* t;                 // n or nullptr             (getRay: n*3 directions out)
+};
+void launch_rays(const RayParams& p, bool get_rays, hipStream_t stream);
+
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);

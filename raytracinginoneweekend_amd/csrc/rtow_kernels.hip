@@ -1083,6 +1083,145 @@ void launch_arithmetic_selftest(unsigned long long* mismatches, hipStream_t stre
   hipLaunchKernelGGL(arithmetic_selftest_kernel, dim3(256 * 8), dim3(256), 0, stream, mismatches);
 }
 
+// ------------------------------------------------------------------ single rays (rayColor / hit / getRay)
+// One lane per ray, no scheduling: the reference's per-ray procs for callers that probe the world ray by
+// ray.  The arithmetic is the renderer's: the first segment in binary64 with the reference's operations
+// (hitrecord.nim:55-71 over hittables.nim:79-88, here for a caller-given [t_min, t_max]), later segments in
+// binary32 with the same screen, exact test and shading functions the trace kernel uses, so a ray traced
+// here gets what the same ray would get as a camera ray inside a render.
+static __device__ __forceinline__ bool sphere_hit_range_f64(double ox, double oy, double oz, double dx, double dy, double dz,
+                                                            double a, double4 sp, double t_min, double t_max, double& root) {
+  const double ocx = ox - sp.x, ocy = oy - sp.y, ocz = oz - sp.z;
+  double half_b = 0.0;
+  half_b += ocx * dx; half_b += ocy * dy; half_b += ocz * dz;
+  const double c = (ocx * ocx + ocy * ocy + ocz * ocz) - sp.w * sp.w;
+  const double disc = half_b * half_b - a * c;
+  if (disc < 0) return false;
+  const double sqrtd = sqrt(disc);
+  root = (-half_b - sqrtd) / a;
+  if (root < t_min || t_max < root) {
+    root = (-half_b + sqrtd) / a;
+    if (root < t_min || t_max < root) return false;
+  }
+  return true;
+}
+
+// closest hit of a binary32 segment, one lane walking the whole list: the screen, then the exact test, then
+// the closest-so-far rule - the arithmetic of scan_regular / cand_drain without the sharing across lanes
+static __device__ __forceinline__ int closest_hit_serial(const RayParams& P, f3 o, f3 u, float tmin, int prev, float& best) {
+  best = INFINITY;
+  int id = -1;
+  for (int k = 0; k < P.n_big; ++k) {
+    const BigSphere bs = P.big[k];
+    float t;
+    const bool ok = big_candidate(o, u, bs, tmin, bs.index == prev, t);
+    offer(ok, t, bs.index, best, id);
+  }
+  const FilterRay fr = filter_ray(o, u, P.cmax);
+  for (int j = 0; j < P.n_list; ++j) {
+    const float nk = P.geom_nk[j];          // -inf for the spheres handled above: they never pass
+    const float4 sp = P.geom_exact[j];      // (cx, cy, cz, r^2)
+    if (!(filter_value(sp.x, sp.y, sp.z, -nk, u, fr) >= fr.threshold)) continue;
+    const float ocx = o.x - sp.x, ocy = o.y - sp.y, ocz = o.z - sp.z;
+    float b = ocx * u.x; b = fmaf(ocy, u.y, b); b = fmaf(ocz, u.z, b);
+    float m = fmaf(-ocx, ocx, sp.w); m = fmaf(-ocy, ocy, m); m = fmaf(-ocz, ocz, m);
+    const float disc = fmaf(b, b, m);
+    float t;
+    const bool ok = regular_candidate(b, disc, tmin, j == prev, t);
+    offer(disc >= 0.0f && ok, t, j, best, id);
+  }
+  return id;
+}
+
+__global__ void __launch_bounds__(256) rtow_rays_kernel(const RayParams P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const double ox = P.orig[3 * i], oy = P.orig[3 * i + 1], oz = P.orig[3 * i + 2];
+  const double dx = P.dir[3 * i], dy = P.dir[3 * i + 1], dz = P.dir[3 * i + 2];
+  const double a = dx * dx + dy * dy + dz * dz;
+  // ---- hit(world, r, t_min, t_max, rec) in binary64, list order, shrinking t_max
+  f3 o = {(float)ox, (float)oy, (float)oz};
+  f3 d = {(float)dx, (float)dy, (float)dz};
+  f3 u;
+  float tmin;
+  segment_begin(d, u, tmin);
+  const FilterRay fr = filter_ray(o, u, P.cmax);
+  double closest = P.t_max;
+  int id = -1;
+  for (int j = 0; j < P.n_list; ++j) {
+    const float nk = P.geom_nk[j];
+    if (nk != -INFINITY) {   // a binary32-table sphere: the render's screen runs first (it only drops misses)
+      const float4 sp = P.geom_exact[j];
+      if (!(filter_value(sp.x, sp.y, sp.z, -nk, u, fr) >= fr.threshold)) continue;
+    }
+    double root;
+    if (sphere_hit_range_f64(ox, oy, oz, dx, dy, dz, a, P.geom64[j], P.t_min, closest, root)) { closest = root; id = j; }
+  }
+  if (P.hit_id) P.hit_id[i] = id;
+  if (P.t) P.t[i] = id >= 0 ? closest : INFINITY;
+  if (!P.color || P.max_depth <= 0) {
+    if (P.color) { P.color[3 * i] = 0.0; P.color[3 * i + 1] = 0.0; P.color[3 * i + 2] = 0.0; }   // depth <= 0 (raytracer.nim:8-9)
+    return;
+  }
+  // ---- rayColor(r, world, depth) (raytracer.nim:5-20); the stream is that of path (pixel i, sample 0)
+  double cr = 0.0, cg = 0.0, cb = 0.0;
+  if (id < 0) {
+    const double uy = dy / sqrt(a);
+    const double ts = 0.5 * (uy + 1.0);
+    const double w1 = (1.0 - ts) * 1.0;
+    cr = w1 + ts * 0.5; cg = w1 + ts * 0.7; cb = w1 + ts * 1.0;
+  } else {
+    Stream g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)i, 0u);
+    float tr = 1.0f, tg = 1.0f, tb = 1.0f;
+    f3 p = {(float)(ox + closest * dx), (float)(oy + closest * dy), (float)(oz + closest * dz)};
+    f3 dn;
+    bool alive = shade_at(P.shade[id], p, u, g, dn, tr, tg, tb);
+    int prev = id;
+    o = p;
+    for (int depth = P.max_depth - 1; alive && depth > 0; --depth) {
+      segment_begin(dn, u, tmin);
+      float best;
+      const int h = closest_hit_serial(P, o, u, tmin, prev, best);
+      if (h < 0) {
+        float rr, rg, rb;
+        shade_sky(u, tr, tg, tb, rr, rg, rb);
+        cr = rr; cg = rg; cb = rb;
+        break;
+      }
+      alive = shade_hit(P.shade[h], o, u, best, g, dn, tr, tg, tb);
+      prev = h;
+    }
+  }
+  P.color[3 * i] = cr; P.color[3 * i + 1] = cg; P.color[3 * i + 2] = cb;
+}
+
+// getRay(camera, s, t) (camera.nim:34-39) for n (s, t) pairs in binary64; ray i draws its lens sample
+// (basetypes.nim:130-134) from the stream of path (pixel i, sample 0), starting at that stream's first draw
+__global__ void __launch_bounds__(256) rtow_get_rays_kernel(const RayParams P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  Stream g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)i, 0u);
+  int ax, ay;
+  do {
+    ax = (int)(draw_u32(g) >> 8) - (1 << 23); ay = (int)(draw_u32(g) >> 8) - (1 << 23);
+  } while ((long long)ax * ax + (long long)ay * ay >= (1ll << 46));
+  const double lens = P.cam.lens_radius;
+  const double rdx = lens * ((double)ax * 0x1p-23), rdy = lens * ((double)ay * 0x1p-23);
+  const double cs = P.orig[i], ct = P.dir[i];   // the s and t arrays travel in the two input slots
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double off = P.cam.u[k] * rdx + P.cam.v[k] * rdy;
+    P.color[3 * i + k] = P.cam.origin[k] + off;
+    P.t[3 * i + k] = P.cam.llc[k] + cs * P.cam.hor[k] + ct * P.cam.ver[k] - P.cam.origin[k] - off;
+  }
+}
+
+void launch_rays(const RayParams& p, bool get_rays, hipStream_t stream) {
+  if (p.n <= 0) return;
+  if (get_rays) hipLaunchKernelGGL(rtow_get_rays_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(rtow_rays_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+}
+
 #ifdef RTOW_GUARD
 extern "C" int rtow_debug_guard(unsigned long long* out) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guard), sizeof(g_guard)) != hipSuccess) return -2;

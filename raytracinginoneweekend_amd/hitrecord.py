@@ -4,7 +4,7 @@ The intersection and scatter procs of hitrecord.nim run on the GPU; here are onl
 types a scene is made of.
 """
 from . import _lib
-from .basetypes import Color, Point
+from .basetypes import Color, Point, Vec3, dot
 
 mkLambertian, mkMetal, mkDielectric = _lib.LAMBERTIAN, _lib.METAL, _lib.DIELECTRIC
 
@@ -80,3 +80,22 @@ class Sphere:
         self.center = center if isinstance(center, Point) else Point(*center)
         self.radius = float(radius)
         self.mat = mat if mat is not None else initMaterial(initLambertian(Color(0, 0, 0)))
+
+
+class HitRecord:
+    """hitrecord.nim:4-9"""
+
+    __slots__ = ("p", "normal", "t", "frontFace", "mat", "index")
+
+    def __init__(self):
+        self.p = Point(0, 0, 0)
+        self.normal = Vec3(0, 0, 0)
+        self.t = 0.0
+        self.frontFace = False
+        self.mat = None
+        self.index = -1   # position of the sphere in its list (not in the reference: a debugging aid)
+
+    def setFaceNormal(self, r, outward_normal):
+        """hitrecord.nim:51-53"""
+        self.frontFace = dot(r.dir, outward_normal) < 0
+        self.normal = outward_normal if self.frontFace else -outward_normal

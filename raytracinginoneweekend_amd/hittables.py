@@ -76,3 +76,10 @@ class HittablesList:
 
 def initHittables(size=8):
     return HittablesList(size)
+
+
+def hit(h, r, t_min, t_max, rec):
+    """hit*(h: var HittablesList, r: Ray, t_min, t_max: float, rec: var HitRecord): bool (hittables.nim:79-88);
+    the search over the list runs on the GPU (raytracer.hit)."""
+    from . import raytracer
+    return raytracer.hit(h, r, t_min, t_max, rec)

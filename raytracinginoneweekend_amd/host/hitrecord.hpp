@@ -31,4 +31,17 @@ struct Sphere {  // hitrecord.nim:11-14
   Material mat;
 };
 
+struct HitRecord {  // hitrecord.nim:4-9
+  Point p;
+  Vec3 normal;
+  double t = 0;
+  bool frontFace = false;
+  Material mat;
+  int index = -1;  // position of the sphere in its list (not in the reference: a debugging aid)
+  void setFaceNormal(const Ray& r, const Vec3& outward_normal) {  // hitrecord.nim:51-53
+    frontFace = dot(r.dir, outward_normal) < 0;
+    normal = frontFace ? outward_normal : -outward_normal;
+  }
+};
+
 }  // namespace rtowhost

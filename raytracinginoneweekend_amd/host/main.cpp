@@ -1,6 +1,7 @@
 // Command-line driver: main of raytracer.nim (:113-138) with its constants as defaults.
 //   rtow_raytracer [--width W] [--ratio R] [--spp N] [--depth D] [--scene random|mix|redblue]
 //                  [--half-extent E] [--out file.ppm] [--device K | --devices K0,K1,...] [--dump-scene]
+//                  [--probe S T]   getRay(camera, S, T), then hit and rayColor of that ray: one line of numbers
 // --devices spreads the frame over several GPUs (an index may repeat); the image does not change.
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +16,8 @@ int main(int argc, char** argv) {
   int width = 1200, spp = 500, depth = 50, device = 0, halfExtent = 11;
   double ratio = 3.0 / 2.0;
   std::string out = "/tmp/test_small.ppm", scene = "random";
-  bool dump = false;
+  bool dump = false, probe = false;
+  double probeS = 0.5, probeT = 0.5;
   std::vector<int> devices;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -36,6 +38,7 @@ int main(int argc, char** argv) {
       }
     }
     else if (a == "--dump-scene") dump = true;
+    else if (a == "--probe") { probe = true; probeS = std::atof(val()); probeT = std::atof(val()); }
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
   try {
@@ -54,6 +57,19 @@ int main(int argc, char** argv) {
     const Camera cam = scene == "random" ? bookCamera(ratio)
                        : scene == "mix"  ? initCamera(point(3, 3, 2), point(0, 0, -1), vec3(0, 1, 0), 20, ratio, 2.0, std::sqrt(27.0))
                                          : initCamera(point(0, 0, 0), point(0, 0, -1), vec3(0, 1, 0), 90, ratio, 0.0, 1.0);
+    if (probe) {  // the reference's per-ray procs through the C++ host: getRay, hit, rayColor
+      Device dev(device);
+      dev.setWorld(world);
+      dev.setCamera(cam);
+      const Ray r = getRay(dev, probeS, probeT);
+      HitRecord rec;
+      const bool h = hit(world, dev, r, 0.001, INFINITY, rec);
+      const Color c = rayColor(r, dev, depth);
+      std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %.17g %.17g %.17g\n",
+                  r.orig[0], r.orig[1], r.orig[2], r.dir[0], r.dir[1], r.dir[2], (int)h, rec.index, rec.t, rec.p[0], rec.p[1],
+                  rec.p[2], rec.normal[0], rec.normal[1], rec.normal[2], (int)rec.frontFace, c[0], c[1], c[2]);
+      return 0;
+    }
     if (!devices.empty()) {
       uint64_t segments = 0;
       renderMulti(img, out, world, cam, spp, depth, devices, kRenderSeed, &segments);

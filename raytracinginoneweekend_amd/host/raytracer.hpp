@@ -2,6 +2,7 @@
 // writer.  render() keeps the reference's signature; its j/i/s loops (raytracer.nim:36-45) are
 // one call into librtow_hip.so.
 #pragma once
+#include <cmath>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -92,6 +93,59 @@ inline std::vector<uint8_t> renderMulti(const Image& img, const std::string& f, 
   destroyAll();
   if (!f.empty()) writePPM(f, img.width, img.height, rgb);
   return rgb;
+}
+
+// A context that holds one world and one camera for the per-ray procs below (they would otherwise upload
+// the scene for every ray).  The reference's procs take the world / camera by value; these take a Device.
+class Device {
+ public:
+  explicit Device(int device = 0) { check(rtow_create(device, &ctx_), "rtow_create"); }
+  ~Device() { rtow_destroy(ctx_); }
+  Device(const Device&) = delete;
+  Device& operator=(const Device&) = delete;
+  void setWorld(const HittablesList& world) {
+    const HittablesList::Flat s = world.flatten();
+    check(rtow_set_scene_f64(ctx_, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
+                             s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene_f64");
+  }
+  void setCamera(const Camera& camera) {
+    const rtow_camera_f64 cam = camera.flat();
+    check(rtow_set_camera_f64(ctx_, &cam), "rtow_set_camera_f64");
+  }
+  rtow_ctx* ctx() const { return ctx_; }
+ private:
+  rtow_ctx* ctx_ = nullptr;
+};
+
+// rayColor*(r, world, depth)  (raytracer.nim:5-20): the world is the one `dev` holds; scattering draws from the
+// stream of path (pixel 0, sample 0) of `seed` instead of the reference's global generator
+inline Color rayColor(const Ray& r, Device& dev, int depth, uint64_t seed = kRenderSeed) {
+  double c[3];
+  check(rtow_trace_rays(dev.ctx(), 1, r.orig.arr.data(), r.dir.arr.data(), 0.001, INFINITY, depth, seed, c, nullptr, nullptr), "rtow_trace_rays");
+  return color(c[0], c[1], c[2]);
+}
+
+// hit*(h, r, t_min, t_max, rec)  (hittables.nim:79-88): the search runs on the GPU over the list `dev` holds (which
+// must be `h`); the record is completed as Sphere.hit does (hitrecord.nim:73-77)
+inline bool hit(const HittablesList& h, Device& dev, const Ray& r, double t_min, double t_max, HitRecord& rec) {
+  int32_t id = -1;
+  double t = 0;
+  check(rtow_trace_rays(dev.ctx(), 1, r.orig.arr.data(), r.dir.arr.data(), t_min, t_max, 0, kRenderSeed, nullptr, &id, &t), "rtow_trace_rays");
+  if (id < 0) return false;
+  const Sphere& s = h[id].hSphere;
+  rec.t = t;
+  rec.p = at(r, t);
+  rec.setFaceNormal(r, (rec.p - s.center) / s.radius);
+  rec.mat = s.mat;
+  rec.index = id;
+  return true;
+}
+
+// getRay*(c, s, t)  (camera.nim:34-39) for the camera `dev` holds
+inline Ray getRay(Device& dev, double s, double t, uint64_t seed = kRenderSeed) {
+  Ray r;
+  check(rtow_get_rays(dev.ctx(), 1, &s, &t, seed, r.orig.arr.data(), r.dir.arr.data()), "rtow_get_rays");
+  return r;
 }
 
 inline HittablesList sceneRedBlue() {  // raytracer.nim:48-59

@@ -9,9 +9,9 @@ import sys
 import numpy as np
 
 from . import _lib, nimrandom
-from .basetypes import Color, Image, Point, color, length, point, randomVec, vec3
+from .basetypes import Color, Image, Point, Ray, Vec3, color, length, point, randomVec, vec3
 from .camera import Camera, initCamera
-from .hitrecord import (Sphere, initDielectric, initLambertian, initMaterial, initMetal)
+from .hitrecord import (HitRecord, Sphere, initDielectric, initLambertian, initMaterial, initMetal)  # noqa: F401
 from .hittables import HittablesList, initHittables
 
 RENDER_SEED = 0xE7  # raytracer.nim:135
@@ -110,6 +110,36 @@ class Renderer:
                                                rows_p, n_rows, rgb_dev))
         self._last_shape = (n_rows, width)
 
+    def traceRays(self, origins, directions, maxDepth, t_min=0.001, t_max=math.inf, seed=RENDER_SEED,
+                  want_color=True, want_hit=True):
+        """rayColor / hit for a batch of rays (rtow_trace_rays): origins, directions float64 [n, 3].
+        Returns (color float64 [n, 3] | None, hit_id int32 [n] | None, t float64 [n] | None); ray i scatters
+        with the stream of path (pixel i, sample 0).  maxDepth = 0 answers the hit query only."""
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        if o.shape != d.shape:
+            raise ValueError("traceRays: origins and directions differ in shape")
+        n = o.shape[0]
+        col = np.zeros((n, 3), np.float64) if want_color else None
+        hid = np.full(n, -1, np.int32) if want_hit else None
+        t = np.full(n, np.inf, np.float64) if want_hit else None
+        ptr = lambda a: a.ctypes.data if a is not None and a.size else None  # noqa: E731
+        self._check(self._lib.rtow_trace_rays(self._h, n, ptr(o), ptr(d), float(t_min), float(t_max), int(maxDepth), seed,
+                                              ptr(col), ptr(hid), ptr(t)))
+        return col, hid, t
+
+    def getRays(self, s, t, seed=RENDER_SEED):
+        """getRay for a batch of (s, t) (rtow_get_rays): returns (origins, directions) float64 [n, 3]."""
+        s = np.ascontiguousarray(s, dtype=np.float64).reshape(-1)
+        t = np.ascontiguousarray(t, dtype=np.float64).reshape(-1)
+        if s.shape != t.shape:
+            raise ValueError("getRays: s and t differ in length")
+        n = s.shape[0]
+        o, d = np.zeros((n, 3), np.float64), np.zeros((n, 3), np.float64)
+        ptr = lambda a: a.ctypes.data if a.size else None  # noqa: E731
+        self._check(self._lib.rtow_get_rays(self._h, n, ptr(s), ptr(t), seed, ptr(o), ptr(d)))
+        return o, d
+
     def renderNoAlloc(self, width, height, samplesPerPixel, maxDepth, rgb_dev, seed=RENDER_SEED, rows_dev=None,
                       n_rows=None):
         """Enqueue a render that allocates nothing (rtow_render_noalloc): rgb_dev and rows_dev are
@@ -175,6 +205,62 @@ def renderMulti(renderers, width, height, samplesPerPixel, maxDepth, seed=RENDER
     _lib.check(L.rtow_render_multi(handles, len(renderers), width, height, samplesPerPixel, maxDepth, seed, tile,
                                    rgb.ctypes.data, C.byref(seg)))
     return rgb, seg.value
+
+
+# ---- the reference's per-ray procs, one ray at a time, on a context this module keeps ----------------------
+_shared = {"renderer": None, "world": None, "camera": None}
+
+
+def _shared_renderer(world=None, camera=None):
+    """The module's own Renderer (device 0), holding `world` / `camera` (uploaded again only when another
+    object is passed)."""
+    if _shared["renderer"] is None:
+        _shared["renderer"] = Renderer(0)
+    r = _shared["renderer"]
+    if world is not None and (_shared["world"] is not world or _shared.get("world_len") != len(world)):
+        r.setWorld(world)
+        _shared["world"], _shared["world_len"] = world, len(world)
+    if camera is not None and _shared["camera"] is not camera:
+        r.setCamera(camera)
+        _shared["camera"] = camera
+    return r
+
+
+def rayColor(r, world, depth, seed=RENDER_SEED, index=0):
+    """rayColor*(r: Ray, world: var HittablesList, depth: int): Color (raytracer.nim:5-20).  Scattering
+    draws from the stream of path (pixel `index`, sample 0) of `seed` instead of the global generator."""
+    dev = _shared_renderer(world=world)
+    n = index + 1   # ray i of a batch uses stream i: place the ray at position `index`
+    o = np.tile(np.asarray(list(r.orig), np.float64), (n, 1))
+    d = np.tile(np.asarray(list(r.dir), np.float64), (n, 1))
+    col, _, _ = dev.traceRays(o, d, depth, seed=seed, want_hit=False)
+    return Color(*col[index])
+
+
+def hit(world, r, t_min, t_max, rec):
+    """hit*(h: var HittablesList, r: Ray, t_min, t_max: float, rec: var HitRecord): bool
+    (hittables.nim:79-88).  The closest-hit search runs on the GPU; the record is completed here as
+    Sphere.hit does (hitrecord.nim:73-77)."""
+    dev = _shared_renderer(world=world)
+    _, hid, t = dev.traceRays([list(r.orig)], [list(r.dir)], 0, t_min=t_min, t_max=t_max, want_color=False)
+    if hid[0] < 0:
+        return False
+    s = world[int(hid[0])].hSphere
+    rec.t = float(t[0])
+    rec.p = r.at(rec.t)
+    rec.setFaceNormal(r, (Vec3(*rec.p) - Vec3(*s.center)) / s.radius)
+    rec.mat = s.mat
+    rec.index = int(hid[0])
+    return True
+
+
+def getRay(c, s, t, seed=RENDER_SEED, index=0):
+    """getRay*(c: Camera, s, t: float): Ray (camera.nim:34-39); the lens sample comes from the stream of
+    path (pixel `index`, sample 0)."""
+    dev = _shared_renderer(camera=c)
+    n = index + 1
+    o, d = dev.getRays([s] * n, [t] * n, seed=seed)
+    return Ray(Point(*o[index]), Vec3(*d[index]))
 
 
 def writeColor(f, color, samplesPerPixel):

@@ -1,0 +1,199 @@
+"""The reference's per-ray procs on the GPU - hit (hittables.nim:79, hitrecord.nim:55), rayColor
+(raytracer.nim:5), getRay (camera.nim:34) - through rtow_trace_rays / rtow_get_rays, against the oracle's
+single-ray probes.  The first world.hit of a ray is evaluated in binary64 with the reference's operations, so
+hit index and t must EQUAL the FP64 restatement's (oracle/ref64.c); colours must equal the renderer's CPU
+mirror bit for bit, and the FP64 restatement's exactly at depth 1 and closely at depth 50."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _R():
+    from raytracinginoneweekend_amd import raytracer
+    return raytracer
+
+
+def _rays(rng, n, scale=14.0):
+    """Rays that start around the scene and point roughly at it (most hit something), with directions of any length."""
+    o = rng.normal(0.0, scale / 2, (n, 3))
+    o[:, 1] = np.abs(o[:, 1]) + 0.05
+    target = rng.normal(0.0, 4.0, (n, 3)) * np.array([1.0, 0.05, 1.0]) + np.array([0.0, 0.3, 0.0])
+    d = (target - o) * np.exp(rng.uniform(-3.0, 3.0, (n, 1)))
+    return o, d
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_hit_equals_the_fp64_restatement(gpu_renderer, oracle, book_scene):
+    arr, n = book_scene
+    R = _R()
+    gpu_renderer.setWorld(R.randomScene())
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    o, d = _rays(rng, 3000)
+    for t_min, t_max in ((0.001, math.inf), (0.25, 0.9), (1e-9, 1e9)):
+        _, hid, t = gpu_renderer.traceRays(o, d, 0, t_min=t_min, t_max=t_max, want_color=False)
+        hits = 0
+        for i in range(len(o)):
+            tt = C.c_double(0.0)
+            want = L.orc_ref64_world_hit(arr, n, _dp(o[i]), _dp(d[i]), t_min, t_max, C.byref(tt))
+            assert hid[i] == want, (i, hid[i], want)
+            if want >= 0:
+                assert t[i] == tt.value, (i, t[i], tt.value)   # same bits: t in units of |dir|
+                hits += 1
+            else:
+                assert t[i] == math.inf
+        assert hits > (1000 if t_max == math.inf else 50)
+    # the hollow glass shell (negative radius), the radius-100 ground and two coincident spheres (later index wins)
+    arr2, n2 = oracle.spheres_from_arrays([(0, -100.5, -1), (0, 0, -1), (-1, 0, -1), (-1, 0, -1), (1, 0, -1), (1, 0, -1)],
+                                          [100, 0.5, 0.5, -0.4, 0.5, 0.5], [0, 0, 2, 2, 1, 0],
+                                          [(0.8, 0.8, 0.0), (0.1, 0.2, 0.5), (1, 1, 1), (1, 1, 1), (0.8, 0.6, 0.2), (0.3, 0.3, 0.3)],
+                                          [0, 0, 0, 0, 1.0, 0], [1.0, 1.0, 1.5, 1.5, 1.0, 1.0])
+    with R.Renderer(0) as r:
+        r.setWorld({"center_x": [0, 0, -1, -1, 1, 1], "center_y": [-100.5, 0, 0, 0, 0, 0], "center_z": [-1] * 6,
+                    "radius": [100, 0.5, 0.5, -0.4, 0.5, 0.5], "kind": [0, 0, 2, 2, 1, 0],
+                    "albedo": [(0.8, 0.8, 0.0), (0.1, 0.2, 0.5), (1, 1, 1), (1, 1, 1), (0.8, 0.6, 0.2), (0.3, 0.3, 0.3)],
+                    "fuzz": [0, 0, 0, 0, 1.0, 0], "ir": [1.0, 1.0, 1.5, 1.5, 1.0, 1.0]})
+        o2 = rng.normal(0.0, 1.5, (2000, 3)) + np.array([0.0, 0.6, 1.0])
+        d2 = np.array([0.0, 0.0, -1.0]) + rng.normal(0.0, 0.6, (2000, 3))
+        _, hid, t = r.traceRays(o2, d2, 0, want_color=False)
+        for i in range(len(o2)):
+            tt = C.c_double(0.0)
+            want = L.orc_ref64_world_hit(arr2, n2, _dp(o2[i]), _dp(d2[i]), 0.001, math.inf, C.byref(tt))
+            assert hid[i] == want and (want < 0 or t[i] == tt.value), (i, hid[i], want)
+        assert 5 in hid and 4 not in hid and 2 in hid and 0 in hid    # of the coincident pair only the later entry is ever hit
+
+
+def test_ray_color_equals_mirror_and_tracks_fp64(gpu_renderer, oracle, book_scene):
+    arr, n = book_scene
+    R = _R()
+    gpu_renderer.setWorld(R.randomScene())
+    L = oracle.lib()
+    rng = np.random.default_rng(12)
+    o, d = _rays(rng, 600)
+    for depth in (1, 2, 50):
+        col, hid, t = gpu_renderer.traceRays(o, d, depth, seed=0xE7)
+        close = 0
+        for i in range(len(o)):
+            c = (C.c_double * 3)()
+            tt = C.c_double(0.0)
+            want = L.orc_mirror32_trace_ray(arr, n, _dp(o[i]), _dp(d[i]), 0.001, math.inf, depth, 0xE7, i, c, C.byref(tt))
+            assert hid[i] == want and list(col[i]) == list(c), (depth, i, list(col[i]), list(c))
+            f = (C.c_double * 3)()
+            L.orc_ref64_ray_color(arr, n, _dp(o[i]), _dp(d[i]), depth, 0xE7, i, f)
+            if depth == 1:
+                assert list(col[i]) == list(f), (i, list(col[i]), list(f))   # black, or the binary64 sky colour
+            close += max(abs(col[i][k] - f[k]) for k in range(3)) < 1e-4
+        assert close >= 0.97 * len(o), (depth, close)   # same streams: the same path almost always, then ~1e-6 apart
+    assert (col.max(axis=1) > 0).sum() > 300
+
+
+def test_get_rays_equal_the_fp64_restatement(gpu_renderer, oracle):
+    R = _R()
+    L = oracle.lib()
+    rng = np.random.default_rng(13)
+    for aspect, kw in ((1.5, {}), (16 / 9, {"look_from": (3, 3, 2), "look_at": (0, 0, -1), "vfov": 20.0, "aperture": 2.0,
+                                            "focus": math.sqrt(27.0)})):
+        cam = oracle.book_camera(aspect, **kw)
+        from raytracinginoneweekend_amd.basetypes import point, vec3
+        from raytracinginoneweekend_amd.camera import initCamera
+        hc = R.bookCamera(aspect) if not kw else initCamera(point(3, 3, 2), point(0, 0, -1), vec3(0, 1, 0), 20.0, aspect,
+                                                              aperture=2.0, focusDist=math.sqrt(27.0))
+        gpu_renderer.setCamera(hc)
+        s, t = rng.uniform(-0.1, 1.1, 500), rng.uniform(-0.1, 1.1, 500)
+        og, dg = gpu_renderer.getRays(s, t, seed=0xE7)
+        for i in range(len(s)):
+            key = (C.c_uint32 * 2)()
+            L.orc_path_key(0xE7, i, 0, key)
+            k = C.c_uint32(0)
+            oo, dd = (C.c_double * 3)(), (C.c_double * 3)()
+            L.orc_ref64_get_ray(C.byref(cam), s[i], t[i], key, C.byref(k), oo, dd)
+            assert list(og[i]) == list(oo) and list(dg[i]) == list(dd), i
+            assert k.value >= 2
+
+
+def test_reference_signatures(oracle, book_scene):
+    """rayColor(r, world, depth), hit(world, r, t_min, t_max, rec), getRay(camera, s, t) as the reference spells them."""
+    arr, n = book_scene
+    R = _R()
+    from raytracinginoneweekend_amd import camera as cam_mod, hittables as HT
+    from raytracinginoneweekend_amd.basetypes import Color, initRay, point, vec3
+    from raytracinginoneweekend_amd.hitrecord import HitRecord
+    L = oracle.lib()
+    world = R.randomScene()
+    cam = R.bookCamera(1.5)
+    r = cam_mod.getRay(cam, 0.5, 0.45)
+    rec = HitRecord()
+    assert HT.hit(world, r, 0.001, math.inf, rec) is True
+    o, d = np.array(list(r.orig)), np.array(list(r.dir))
+    tt, pp, nn, ff = C.c_double(0), (C.c_double * 3)(), (C.c_double * 3)(), C.c_int(0)
+    assert L.orc_ref64_sphere_hit(C.byref(arr[rec.index]), _dp(o), _dp(d), 0.001, math.inf, C.byref(tt), pp, nn, C.byref(ff)) == 1
+    assert rec.t == tt.value and list(rec.p) == list(pp) and list(rec.normal) == list(nn) and rec.frontFace == bool(ff.value)
+    assert rec.mat is world[rec.index].hSphere.mat
+    up = initRay(point(0, 5, 0), vec3(0, 1, 0))
+    assert HT.hit(world, up, 0.001, math.inf, HitRecord()) is False
+    c = R.rayColor(up, world, 50)
+    assert isinstance(c, Color) and list(c) == [0.5, 0.7, 1.0]            # straight up: t = 1 in raytracer.nim:18-20
+    assert list(R.rayColor(up, world, 0)) == [0.0, 0.0, 0.0]              # depth <= 0 (raytracer.nim:8-9)
+    down = initRay(point(0, 5, 0), vec3(0.3, -1, 0.2))
+    f = (C.c_double * 3)()
+    L.orc_ref64_ray_color(arr, n, _dp(np.array(list(down.orig))), _dp(np.array(list(down.dir))), 50, 0xE7, 3, f)
+    got = R.rayColor(down, world, 50, index=3)
+    assert max(abs(got[k] - f[k]) for k in range(3)) < 1e-4
+
+
+def test_cpp_host_per_ray_procs(oracle, book_scene):
+    """getRay, hit and rayColor of the compiled host (raytracinginoneweekend_amd/host) through its CLI."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    arr, n = book_scene
+    L = oracle.lib()
+    exe = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "rtow_raytracer")
+    cam = oracle.book_camera(1.5)
+    for s_, t_ in ((0.5, 0.45), (0.2, 0.9), (0.9, 0.2)):
+        v = subprocess.check_output([exe, "--probe", repr(s_), repr(t_), "--depth", "50"], text=True).split()
+        o, d = np.array([float(x) for x in v[0:3]]), np.array([float(x) for x in v[3:6]])
+        key = (C.c_uint32 * 2)()
+        L.orc_path_key(0xE7, 0, 0, key)
+        k = C.c_uint32(0)
+        oo, dd = (C.c_double * 3)(), (C.c_double * 3)()
+        L.orc_ref64_get_ray(C.byref(cam), s_, t_, key, C.byref(k), oo, dd)
+        assert list(o) == list(oo) and list(d) == list(dd)
+        tt = C.c_double(0.0)
+        want = L.orc_ref64_world_hit(arr, n, _dp(o), _dp(d), 0.001, math.inf, C.byref(tt))
+        assert int(v[6]) == (want >= 0) and int(v[7]) == want
+        if want >= 0:
+            pp, nn, ff = (C.c_double * 3)(), (C.c_double * 3)(), C.c_int(0)
+            assert L.orc_ref64_sphere_hit(C.byref(arr[want]), _dp(o), _dp(d), 0.001, math.inf, C.byref(tt), pp, nn, C.byref(ff)) == 1
+            assert float(v[8]) == tt.value and [float(x) for x in v[9:12]] == list(pp)
+            assert [float(x) for x in v[12:15]] == list(nn) and int(v[15]) == ff.value
+        c = (C.c_double * 3)()
+        L.orc_mirror32_trace_ray(arr, n, _dp(o), _dp(d), 0.001, math.inf, 50, 0xE7, 0, c, C.byref(tt))
+        assert [float(x) for x in v[16:19]] == list(c)
+
+
+def test_ray_entry_point_errors(gpu_renderer):
+    from raytracinginoneweekend_amd import _lib
+    R = _R()
+    one = np.zeros((1, 3))
+    with pytest.raises(_lib.RtowError) as e:
+        gpu_renderer.traceRays(one, one + 1, -1)
+    assert e.value.status == -1
+    with pytest.raises(_lib.RtowError):
+        gpu_renderer.traceRays(one, one + 1, 1, t_min=2.0, t_max=1.0)
+    col, hid, t = gpu_renderer.traceRays(np.zeros((0, 3)), np.zeros((0, 3)), 5)
+    assert col.shape == (0, 3) and hid.shape == (0,)
+    with R.Renderer(0) as fresh:
+        with pytest.raises(_lib.RtowError) as e:
+            fresh.traceRays(one, one + 1, 1)
+        assert e.value.status == -3
+        with pytest.raises(_lib.RtowError) as e:
+            fresh.getRays([0.5], [0.5])
+        assert e.value.status == -3
