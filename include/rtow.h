@@ -207,7 +207,11 @@ int rtow_get_rays(rtow_ctx* ctx, int n, const double* s, const double* t, uint64
  * (raytracer.nim:36) - are dealt to the contexts in interleaved tiles of tile_rows rows (tile t goes
  * to context t mod n_ctx), every context renders its rows as rtow_render_async does, and the 8-bit
  * rows are copied into rgb_out (host, h*w*3 bytes, top row first).  The image is byte-identical to
- * what rtow_render produces on one context.  ray_segments_out (may be NULL) receives the total
+ * what rtow_render produces on one context.  When the contexts sit on pairwise different GPUs the rows
+ * are gathered device to device over RCCL (xGMI) onto the first context's GPU - all sends and receives
+ * enqueued before anything is waited for - and reach the host in one copy; librccl.so is opened at
+ * that moment (the copy already in the process, else the system's) and, if it cannot be, every
+ * context's rows are copied to the host in turn, as they are for contexts that share a GPU.  ray_segments_out (may be NULL) receives the total
  * number of world.hit queries.  Each context's rtow_get_stats then describes its own share.
  * Hosts that run one PROCESS per GPU use rtow_render_async with their own row list instead and
  * exchange the rows themselves (the Python host does so with torch.distributed over RCCL). */

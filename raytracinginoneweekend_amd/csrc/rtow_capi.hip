@@ -5,6 +5,10 @@
 #include "rtow_kernels.h"
 
 #include <algorithm>
+#include <dlfcn.h>
+#include <map>
+#include <mutex>
+#include <rccl/rccl.h>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -70,6 +74,50 @@ namespace {
 std::atomic<unsigned char*> g_scratch_ptr[kMaxDevices];
 }  // namespace
 
+// RCCL, bound at run time: the library is only needed by rtow_render_multi on two or more GPUs, so it is
+// opened on first use (the copy already in the process - a host such as PyTorch brings its own - or the
+// system one) instead of being a load-time dependency of every user of this library.
+namespace {
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::map<std::vector<int>, std::vector<ncclComm_t>> comms;   // one clique per ordered device list, kept for the process
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;   // guards g_rccl: communicator creation is rare, collectives on one clique are serialised
+
+// nullptr on success, otherwise what is missing
+const char* rccl_load() {
+  if (g_rccl.handle) return nullptr;
+  void* h = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return "librccl.so not found";
+  Rccl r;
+  r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+  r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
+  r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString)
+    return "librccl.so lacks a symbol";
+  r.handle = h;
+  r.comms.swap(g_rccl.comms);
+  g_rccl = std::move(r);
+  return nullptr;
+}
+}  // namespace
+
 struct rtow_ctx {
   int device = 0;
   int n_cu = 0;
@@ -90,6 +138,9 @@ struct rtow_ctx {
   bool image_in_workspace = false;            // the last render left its 8-bit image in `rgb`
   bool sums_in_workspace = false;             // ... and its radiance sums in `accum`
   DevBuf ray_in, ray_out;                     // staging of rtow_trace_rays / rtow_get_rays
+  DevBuf gather;                              // rtow_render_multi over RCCL: the other GPUs' rows land here (context 0)
+  uint8_t* gather_host = nullptr;             // pinned copy of it
+  size_t gather_host_cap = 0;
   DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
   unsigned char* scratch_dev = nullptr;       // this GPU's copy of the no-allocation work memory
   uint64_t* host_counters = nullptr;          // pinned, 16 bytes
@@ -186,7 +237,8 @@ int rtow_destroy(rtow_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
-  c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release(); c->ray_in.release(); c->ray_out.release();
+  c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release(); c->ray_in.release(); c->ray_out.release(); c->gather.release();
+  if (c->gather_host) (void)hipHostFree(c->gather_host);
   if (c->host_counters) (void)hipHostFree(c->host_counters);
   for (int k = 0; k < 2; ++k) {
     if (c->staging[k]) (void)hipHostFree(c->staging[k]);
@@ -607,6 +659,76 @@ int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, i
 
 }  // extern "C"
 
+// The framebuffer gather of rtow_render_multi over RCCL.  Every context k > 0 sends its rows (they are still being
+// rendered: the send is ordered behind the render on that context's stream) to the first context's GPU, which
+// receives them side by side; all sends and receives are enqueued in one group before anything is waited for.  Then
+// one copy into pinned host memory and the rows are dealt into the caller's image.
+// Returns RTOW_ERR_STATE (with every context drained) when RCCL cannot be used at all.
+static int gather_rccl(rtow_ctx* const* ctxs, int n_ctx, int w, const std::vector<std::vector<int32_t>>& rows, uint8_t* rgb_out,
+                       uint64_t* ray_segments_out) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  auto drain = [&]() { for (int k = 0; k < n_ctx; ++k) (void)rtow_sync(ctxs[k]); };
+  if (const char* why = rccl_load()) { drain(); return fail(RTOW_ERR_STATE, "rtow_render_multi: %s", why); }
+  std::vector<int> devs((size_t)n_ctx);
+  for (int k = 0; k < n_ctx; ++k) devs[(size_t)k] = ctxs[k]->device;
+  std::vector<ncclComm_t>& comms = g_rccl.comms[devs];
+  if (comms.empty()) {
+    comms.resize((size_t)n_ctx);
+    const ncclResult_t e = g_rccl.CommInitAll(comms.data(), n_ctx, devs.data());
+    if (e != ncclSuccess) {
+      g_rccl.comms.erase(devs);
+      drain();
+      return fail(RTOW_ERR_STATE, "rtow_render_multi: ncclCommInitAll over %d devices: %s", n_ctx, g_rccl.GetErrorString(e));
+    }
+  }
+  const size_t row_bytes = 3 * (size_t)w;
+  size_t slot = 0;   // bytes per context in the receive buffer
+  for (int k = 0; k < n_ctx; ++k) slot = std::max(slot, row_bytes * rows[(size_t)k].size());
+  slot = (slot + 255) & ~(size_t)255;
+  rtow_ctx* c0 = ctxs[0];
+  int rc = RTOW_OK;
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(c0->device));
+    HIP_TRY(c0->gather.reserve(slot * (size_t)n_ctx ? slot * (size_t)n_ctx : 256));
+    if (c0->gather_host_cap < slot * (size_t)n_ctx) {
+      if (c0->gather_host) { (void)hipHostFree(c0->gather_host); c0->gather_host = nullptr; c0->gather_host_cap = 0; }
+      HIP_TRY(hipHostMalloc((void**)&c0->gather_host, slot * (size_t)n_ctx, hipHostMallocDefault));
+      c0->gather_host_cap = slot * (size_t)n_ctx;
+    }
+    ncclResult_t e = g_rccl.GroupStart();
+    for (int k = 1; k < n_ctx && e == ncclSuccess; ++k) {
+      const size_t bytes = row_bytes * rows[(size_t)k].size();
+      if (bytes == 0) continue;
+      e = g_rccl.Send(ctxs[k]->rgb.p, bytes, ncclUint8, 0, comms[(size_t)k], ctxs[k]->stream);
+      if (e == ncclSuccess) e = g_rccl.Recv((char*)c0->gather.p + slot * (size_t)k, bytes, ncclUint8, k, comms[0], c0->stream);
+    }
+    const ncclResult_t e2 = g_rccl.GroupEnd();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return fail(RTOW_ERR_DEVICE, "rtow_render_multi: RCCL send/receive: %s", g_rccl.GetErrorString(e));
+    // the first context's own rows join the others on its own stream, behind its render and the receives
+    HIP_TRY(hipSetDevice(c0->device));
+    const size_t own = row_bytes * rows[0].size();
+    if (own) HIP_TRY(hipMemcpyAsync(c0->gather.p, c0->rgb.p, own, hipMemcpyDeviceToDevice, c0->stream));
+    HIP_TRY(hipMemcpyAsync(c0->gather_host, c0->gather.p, slot * (size_t)n_ctx, hipMemcpyDeviceToHost, c0->stream));
+    return RTOW_OK;
+  };
+  rc = body();
+  uint64_t segments = 0;
+  for (int k = 0; k < n_ctx; ++k) {   // every context is drained even after a failure
+    const int r2 = rtow_sync(ctxs[k]);
+    if (r2 != RTOW_OK && rc == RTOW_OK) rc = r2;
+    segments += ctxs[k]->stats.ray_segments;
+  }
+  if (rc != RTOW_OK) return rc;
+  for (int k = 0; k < n_ctx; ++k) {
+    const std::vector<int32_t>& r = rows[(size_t)k];
+    for (size_t i = 0; i < r.size(); ++i)
+      memcpy(rgb_out + row_bytes * (size_t)r[i], c0->gather_host + slot * (size_t)k + row_bytes * i, row_bytes);
+  }
+  if (ray_segments_out) *ray_segments_out = segments;
+  return RTOW_OK;
+}
+
 static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth, uint64_t seed,
                              int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out) {
   if (!ctxs || n_ctx < 1) return fail(RTOW_ERR_INVALID, "rtow_render_multi: no contexts");
@@ -630,6 +752,28 @@ static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int
       for (int j = 0; j < k; ++j) (void)rtow_sync(ctxs[j]);
       return rc;
     }
+  }
+  // The contexts sit on pairwise different GPUs (two or more): the 8-bit rows travel device to device over RCCL
+  // (xGMI) to the first context's GPU and reach the host in one copy.  Otherwise (several contexts on one GPU,
+  // or a single context) every context's rows are copied to the host in turn.  RTOW_MULTI_GATHER=host forces the
+  // second form, =rccl the first (also for a single context: the clique then has one rank and nothing is sent).
+  bool distinct = n_ctx >= 2;
+  for (int k = 0; k < n_ctx && distinct; ++k)
+    for (int j = 0; j < k; ++j)
+      if (ctxs[j]->device == ctxs[k]->device) { distinct = false; break; }
+  bool use_rccl = distinct;
+  if (const char* e = getenv("RTOW_MULTI_GATHER")) {
+    if (!strcmp(e, "host")) use_rccl = false;
+    else if (!strcmp(e, "rccl")) {
+      bool all_different = true;
+      for (int k = 0; k < n_ctx; ++k)
+        for (int j = 0; j < k; ++j) all_different = all_different && ctxs[j]->device != ctxs[k]->device;
+      use_rccl = all_different;
+    }
+  }
+  if (use_rccl && rgb_out) {
+    const int rc = gather_rccl(ctxs, n_ctx, w, rows, rgb_out, ray_segments_out);
+    if (rc != RTOW_ERR_STATE) return rc;   // RTOW_ERR_STATE: RCCL is not available - the host path below still works
   }
   uint64_t segments = 0;
   int first_error = RTOW_OK;

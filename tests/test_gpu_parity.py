@@ -325,6 +325,52 @@ def test_render_multi_contexts_match_single_context(gpu_renderer, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+def test_render_multi_rccl_gather(gpu_renderer):
+    """rtow_render_multi with the RCCL gather, forced for a single context on one GPU (a clique of one rank: RCCL is
+    loaded, the communicator built, the rows reach the host through the pinned gather buffer)."""
+    R = _R()
+    W, H, spp = 150, 101, 5
+    gpu_renderer.setWorld(R.randomScene())
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    full = gpu_renderer.renderRows(W, H, spp, 50)[0]
+    seg_full = gpu_renderer.stats()["ray_segments"]
+    scene = R.randomScene()
+    os.environ["RTOW_MULTI_GATHER"] = "rccl"
+    try:
+        with R.Renderer(0) as r:
+            r.setWorld(scene); r.setCamera(R.bookCamera(W / H))
+            for _ in range(2):   # the second call reuses the communicator and the buffers
+                rgb, seg = R.renderMulti([r], W, H, spp, 50, tile=4)
+                assert (rgb == full).all() and seg == seg_full
+    finally:
+        del os.environ["RTOW_MULTI_GATHER"]
+
+
+def test_render_multi_rccl_gather_across_gpus(gpu_renderer):
+    """The same with one context per GPU (needs two or more GPUs in the process; the build pool's boxes have one)."""
+    from raytracinginoneweekend_amd import _lib
+    R = _R()
+    W, H, spp = 150, 101, 5
+    gpu_renderer.setWorld(R.randomScene())
+    gpu_renderer.setCamera(R.bookCamera(W / H))
+    full = gpu_renderer.renderRows(W, H, spp, 50)[0]
+    seg_full = gpu_renderer.stats()["ray_segments"]
+    scene = R.randomScene()
+    n_dev = _lib.C.c_int(0)
+    _lib.check(_lib.lib().rtow_device_count(_lib.C.byref(n_dev)))
+    if n_dev.value < 2:
+        pytest.skip("one GPU visible: the device-to-device branch needs two")
+    for n_ctx, tile in ((2, 4), (min(n_dev.value, 8), 1)):
+        rs = []
+        for k in range(n_ctx):
+            r = R.Renderer(k); r.setWorld(scene); r.setCamera(R.bookCamera(W / H)); rs.append(r)
+        for _ in range(2):
+            rgb, seg = R.renderMulti(rs, W, H, spp, 50, tile=tile)
+            assert (rgb == full).all() and seg == seg_full
+        for r in rs:
+            r.close()
+
+
 def test_repeatable_and_seed_dependent(gpu_renderer):
     R = _R()
     gpu_renderer.setCamera(R.bookCamera(1.5))
