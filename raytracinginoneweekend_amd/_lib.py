@@ -66,7 +66,12 @@ def _preload_hip_runtime():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return None
-    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    # the same for RCCL, which rtow_render_multi opens on first use (never at import): name torch's copy
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("RTOW_RCCL_LIB", rccl)
+    path = os.path.join(libdir, "libamdhip64.so")
     if not os.path.exists(path):
         return None
     return C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -92,13 +92,32 @@ struct Rccl {
 Rccl g_rccl;
 std::mutex g_rccl_mutex;   // guards g_rccl: communicator creation is rare, collectives on one clique are serialised
 
+// Communicators are destroyed when the process exits, before the libraries under them unload (a handler
+// registered now runs ahead of the destructors of everything loaded before this point).
+void rccl_shutdown() {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  for (auto& clique : g_rccl.comms)
+    for (ncclComm_t comm : clique.second)
+      if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+  g_rccl.comms.clear();
+}
+
 // nullptr on success, otherwise what is missing
 const char* rccl_load() {
   if (g_rccl.handle) return nullptr;
-  void* h = nullptr;
+  // Order: a copy already in the process (a second, different librccl beside it ends badly: both answer to the
+  // soname librccl.so.1, and whoever is loaded first is handed to the other's users), then the file the host
+  // names in RTOW_RCCL_LIB (the Python package points it at PyTorch's bundled copy, so that a later
+  // `import torch` finds the library it was built with), then the system's.  Local scope: only the entry
+  // points looked up below are used, and RCCL's other symbols must not interpose on libraries loaded later.
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+  if (!h) {
+    const char* named = getenv("RTOW_RCCL_LIB");
+    if (named && *named) h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+  }
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (h) break;
+    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
   }
   if (!h) return "librccl.so not found";
   Rccl r;
@@ -114,6 +133,7 @@ const char* rccl_load() {
   r.handle = h;
   r.comms.swap(g_rccl.comms);
   g_rccl = std::move(r);
+  atexit(rccl_shutdown);
   return nullptr;
 }
 }  // namespace

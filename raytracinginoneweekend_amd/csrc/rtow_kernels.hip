@@ -427,7 +427,7 @@ static __device__ __forceinline__ void scan_sparse(ExactPtr exact, const f4v* nk
 
 // A path that ends with light (the sky) adds its fixed-point radiance to its pixel.  The paths of a wave
 // belong to a handful of pixels at a time (a chunk is a run of consecutive samples), so the sums are
-// collected in a small per-wave cache in LDS first - four direct-mapped slots of three 64-bit words,
+// collected in a small per-wave cache in LDS first - four slots of three 64-bit words,
 // filled with LDS atomics - and a slot goes to the frame (three 64-bit global atomics) when another
 // pixel claims it or the wave ends: one set of global atomics per pixel and wave.  Integer sums do not
 // depend on the order they arrive in.  (Sums kept per lane in registers and handed over when the lane
@@ -443,6 +443,7 @@ constexpr uint32_t kNoPixel = 0xffffffffu;
 struct SumCache {
   lds_u64_ptr words;             // this wave's kSumSlots * 3 words
   uint32_t tag[kSumSlots];       // the pixel each slot holds
+  uint32_t victim;               // the slot the next new pixel takes (round robin)
 #ifdef RTOW_GUARD
   long long n_pixels;
 #endif
@@ -451,6 +452,10 @@ static_assert(kSumSlots == 4, "tag_of / set_tag select among four scalars");
 
 static __device__ __forceinline__ uint32_t tag_of(const SumCache& c, uint32_t slot) {
   return slot == 0u ? c.tag[0] : slot == 1u ? c.tag[1] : slot == 2u ? c.tag[2] : c.tag[3];
+}
+// the slot that holds `pix`, or kSumSlots
+static __device__ __forceinline__ uint32_t slot_of(const SumCache& c, uint32_t pix) {
+  return c.tag[0] == pix ? 0u : c.tag[1] == pix ? 1u : c.tag[2] == pix ? 2u : c.tag[3] == pix ? 3u : kSumSlots;
 }
 static __device__ __forceinline__ void set_tag(SumCache& c, uint32_t slot, uint32_t pix) {
   c.tag[0] = slot == 0u ? pix : c.tag[0]; c.tag[1] = slot == 1u ? pix : c.tag[1];
@@ -476,9 +481,14 @@ static __device__ __forceinline__ void flush_sums(unsigned long long* accum, Sum
   while (todo != 0) {
     const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
     const uint32_t pix = (uint32_t)__builtin_amdgcn_readlane((int)accpix, (int)leader);
-    const uint32_t slot = pix & (kSumSlots - 1u);
-    const uint32_t held = tag_of(c, slot);
-    if (held != pix) {
+    // The cache is fully associative: a wave works on the pixels of its current chunk and of a few paths
+    // left over from earlier chunks, whose pixel numbers are unrelated - mapped directly, two of them on
+    // one slot evict each other with every sample.
+    uint32_t slot = slot_of(c, pix);
+    if (slot == kSumSlots) {
+      slot = c.victim;
+      c.victim = (c.victim + 1u) & (kSumSlots - 1u);
+      const uint32_t held = tag_of(c, slot);
       if (held != kNoPixel) sum_cache_evict(accum, c, slot, held, lane);
       set_tag(c, slot, pix);
     }
@@ -544,6 +554,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     if (lane < kSumCacheDwords) mine[lane] = 0u;   // read back only by this wave, in order
     sums.words = (lds_u64_ptr)(unsigned long long*)mine;
     for (uint32_t k = 0; k < kSumSlots; ++k) sums.tag[k] = kNoPixel;
+    sums.victim = 0;
 #ifdef RTOW_GUARD
     sums.n_pixels = (long long)P.n_rows * P.W;
 #endif

@@ -49,5 +49,25 @@ rows = ["# rocprofv3 --pmc passes, rtow_trace_kernel, one value per dispatch (su
         "counter,per_dispatch_values"]
 for k in sorted(pmc):
     rows.append(k + "," + " ".join(f"{v:.6g}" for v in pmc[k]))
+# figures derived from the LAST dispatch of each pass (a launch that ran alone).  SQ counters count quad-cycles
+# summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+def last(name):
+    return pmc[name][-1] if name in pmc else None
+
+
+need = ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "SQ_WAVES")
+if all(last(n) is not None for n in need):
+    cycles = last("GRBM_GUI_ACTIVE") / 8.0                      # shader clocks the launch lasted
+    simd_cycles = cycles * 1024.0
+    rows.append("")
+    rows.append("# derived (last dispatch of the passes)")
+    rows.append(f"kernel_cycles,{cycles:.6g}")
+    rows.append(f"occupancy_waves_per_simd,{4.0 * last('SQ_WAVE_CYCLES') / simd_cycles:.3f},# 4 x SQ_WAVE_CYCLES / (1024 SIMDs x cycles); waves launched: {last('SQ_WAVES'):.0f}")
+    rows.append(f"valu_busy_fraction,{4.0 * last('SQ_ACTIVE_INST_VALU') / simd_cycles:.3f},# share of SIMD cycles in which a VALU instruction executes")
+    rows.append(f"valu_lane_utilisation,{last('SQ_THREAD_CYCLES_VALU') / (64.0 * last('SQ_ACTIVE_INST_VALU')):.3f},# active lanes per executing VALU instruction / 64 (1 - divergence)")
+    rows.append(f"valu_cycles_per_instruction,{4.0 * last('SQ_ACTIVE_INST_VALU') / last('SQ_INSTS_VALU'):.2f}")
+    f64 = sum(last(n) or 0 for n in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+    if f64:
+        rows.append(f"valu_f64_share_of_instructions,{f64 / last('SQ_INSTS_VALU'):.4f},# fma + add + mul in binary64 (primary segments)")
 open(prefix + "_pmc.csv", "w").write("\n".join(rows) + "\n")
 print("\n".join(lines + rows))
