@@ -20,18 +20,20 @@
 namespace rtow {
 
 #ifdef RTOW_PROFILE_COUNTERS
-// debug build only, summed over waves: [0] lanes entering a group's push path, [3] wave iterations, [4] lanes with a
+// debug build only, summed over waves: [0] slots of the pixel-sum cache written out to the frame, [3] wave iterations, [4] lanes with a
 // path over the BOUNCE iterations, [14] PRIMARY iterations, [9] groups with a survivor in some lane, [10] / [12]
 // rounds of binary32 / binary64 exact tests, [11] rejection-loop trips of the slowest lane; clock cycles:
-// [5] hand-out, [1] [2] [13] set-up, scan, shading of PRIMARY iterations, [6] [7] [8] of BOUNCE iterations, [15] all
-__device__ unsigned long long g_prof[16];
+// [5] hand-out, [1] [2] [13] set-up, scan, shading of PRIMARY iterations, [6] [7] [8] of BOUNCE iterations, [15] all;
+// lanes: [16] BOUNCE segments ending on the sky, [17] [18] [19] hitting a Lambertian / metal / dielectric sphere,
+// [20] rejection-loop trips summed over lanes, [21] [22] PRIMARY rays missing / hitting, [23] lanes taking a pooled path
+__device__ unsigned long long g_prof[32];
 
 // wave-local accumulation (values are wave-uniform), flushed once when the wave retires
-#define RTOW_PROF_DECL unsigned long long prof_[16] = {0}
-#define RTOW_PROF_PARAM , unsigned long long (&prof_)[16]
+#define RTOW_PROF_DECL unsigned long long prof_[32] = {0}
+#define RTOW_PROF_PARAM , unsigned long long (&prof_)[32]
 #define RTOW_PROF_ARG , prof_
 #define RTOW_COUNT(i, v) do { prof_[i] += (unsigned long long)(v); } while (0)
-#define RTOW_PROF_FLUSH() do { if ((threadIdx.x & 63u) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_prof[i_], prof_[i_]); } while (0)
+#define RTOW_PROF_FLUSH() do { if ((threadIdx.x & 63u) == 0) for (int i_ = 0; i_ < 32; ++i_) atomicAdd(&g_prof[i_], prof_[i_]); } while (0)
 #define RTOW_CLOCK() __builtin_amdgcn_s_memtime()
 #elif defined(RTOW_PROFILE_TIMELINE)
 // timeline build: per-wave time stamps only (plain stores to distinct addresses, no shared counters)
@@ -335,7 +337,6 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v 
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
   if (__ballot(mx >= r.ozt.y) != 0) {   // wave-uniform: the list's fill count stays a scalar
     RTOW_COUNT(9, 1);
-    RTOW_COUNT(0, mx >= r.ozt.y ? 1 : 0);
     cand_push(cand, f0.x >= r.ozt.y, j);
     cand_push(cand, f0.y >= r.ozt.y, j + 1);
     cand_push(cand, f1.x >= r.ozt.y, j + 2);
@@ -466,6 +467,9 @@ static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum
                                                        uint32_t pix, uint32_t lane) {
   // LDS serves one wave's requests in order: the adds of earlier instructions are in the words read here
   lds_order();
+#ifdef RTOW_PROFILE_COUNTERS
+  if (lane == 0u) atomicAdd(&g_prof[0], 1ull);
+#endif
   if (lane < 3u) {
     const unsigned long long v = c.words[3u * slot + lane];
     c.words[3u * slot + lane] = 0ull;
@@ -622,6 +626,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           depth = P.max_depth - 1;
           alive = true;
         }
+        RTOW_COUNT(23, min(cnt, avail));
         pool_head += min(cnt, avail);
       }
     }
@@ -693,6 +698,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 
 #ifdef RTOW_PROFILE_COUNTERS
     uint32_t shade_draws = 0;
+    int shade_kind = -2;   // -2 no segment, -1 sky, else the material kind
 #endif
 #if defined(RTOW_PROFILE_COUNTERS) || defined(RTOW_PROFILE_TIMELINE)
     unsigned long long t_scan0 = 0, t_scan1 = 0;
@@ -812,6 +818,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           cont = shade_at(sh, p, su, g2, dn, ptr_, ptg_, ptb_) && P.max_depth > 1;
         }
       }
+      RTOW_COUNT(21, __popcll(__ballot(sky)));
+      RTOW_COUNT(22, __popcll(__ballot(gen && !sky)));
       flush_sums(P.accum, sums, sky, pix2, fr, fg, fb, lane);
       const uint64_t m = __ballot(cont);
       if (cont) {
@@ -869,6 +877,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         if (id < 0 || !RTOW_GUARDED(5, id, P.n_list)) {
           shade_sky(u, tr, tg, tb, rr_, rg_, rb_);
           ended = true;
+#ifdef RTOW_PROFILE_COUNTERS
+          shade_kind = -1;
+#endif
         } else {
           const SphereShade sh = P.shade[id];
           f3 dn;
@@ -878,6 +889,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           const bool scattered = shade_hit(sh, o, u, best, g, dn, tr, tg, tb);
 #ifdef RTOW_PROFILE_COUNTERS
           shade_draws = (g.x0 - x0_before) * 0x144cbc89u;
+          shade_kind = sh.kind;
 #endif
           d = dn;
           prev = id;
@@ -897,6 +909,13 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       uint32_t m_ = shade_draws;
       for (int off = 32; off > 0; off >>= 1) { const uint32_t t_ = __shfl_xor(m_, off, 64); m_ = t_ > m_ ? t_ : m_; }
       RTOW_COUNT(11, m_ / 3u);   // rejection-loop trips of the slowest lane
+      RTOW_COUNT(16, __popcll(__ballot(shade_kind == -1)));
+      RTOW_COUNT(17, __popcll(__ballot(shade_kind == kLambertian)));
+      RTOW_COUNT(18, __popcll(__ballot(shade_kind == kMetal)));
+      RTOW_COUNT(19, __popcll(__ballot(shade_kind == kDielectric)));
+      uint32_t t_ = (shade_kind == kLambertian || shade_kind == kMetal) ? shade_draws / 3u : 0u;
+      for (int off = 32; off > 0; off >>= 1) t_ += __shfl_xor(t_, off, 64);
+      RTOW_COUNT(20, t_);
     }
 #endif
 #ifdef RTOW_PROFILE_TIMELINE
@@ -1243,7 +1262,7 @@ extern "C" int rtow_debug_guard(unsigned long long* out) {
 #ifdef RTOW_PROFILE_COUNTERS
 extern "C" int rtow_debug_counters(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -2;
-  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -2; }
   return 0;
 }
 #endif

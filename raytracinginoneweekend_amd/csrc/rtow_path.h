@@ -100,6 +100,24 @@ RTOW_HD float draw(Stream& g) { return (float)(draw_u32(g) >> 8) * (1.0f / 16777
 RTOW_HD float draw_pm1(Stream& g) { return fmaf((float)(draw_u32(g) >> 8), 1.0f / 8388608.0f, -1.0f); }
 
 // randomInUnitSphere (basetypes.nim:114-118): x, y, z drawn in order, rejected while |p|^2 >= 1
+#ifdef RTOW_UNIT_BALL_TWO_TRIPS
+// Experiment: two trips of the rejection loop per pass, evaluated side by side (independent
+// instruction chains); the first accepted one wins and the stream advances exactly as far as the
+// sequential loop would have taken it, so the result is the same bit for bit.
+RTOW_HD f3 unit_ball(Stream& g, float& l2) {
+  for (;;) {
+    Stream a = g;
+    f3 p, q;
+    p.x = draw_pm1(a); p.y = draw_pm1(a); p.z = draw_pm1(a);
+    Stream b = a;
+    q.x = draw_pm1(b); q.y = draw_pm1(b); q.z = draw_pm1(b);
+    const float lp = dot3(p, p), lq = dot3(q, q);
+    if (lp < 1.0f) { g = a; l2 = lp; return p; }
+    g = b;
+    if (lq < 1.0f) { l2 = lq; return q; }
+  }
+}
+#else
 RTOW_HD f3 unit_ball(Stream& g, float& l2) {
   f3 p;
   do {
@@ -108,6 +126,7 @@ RTOW_HD f3 unit_ball(Stream& g, float& l2) {
   } while (l2 >= 1.0f);
   return p;
 }
+#endif
 
 // ------------------------------------------------------------------ camera (camera.nim:4-10,34-39)
 struct CameraParams {
