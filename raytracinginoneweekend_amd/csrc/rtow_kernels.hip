@@ -22,10 +22,10 @@ namespace rtow {
 #ifdef RTOW_PROFILE_COUNTERS
 // debug build only, summed over waves: [0] slots of the pixel-sum cache written out to the frame, [3] wave iterations, [4] lanes with a
 // path over the BOUNCE iterations, [14] PRIMARY iterations, [9] groups with a survivor in some lane, [10] / [12]
-// rounds of binary32 / binary64 exact tests, [11] rejection-loop trips of the slowest lane; clock cycles:
+// rounds of binary32 / binary64 exact tests, [11] passes of the shared rejection loop; clock cycles:
 // [5] hand-out, [1] [2] [13] set-up, scan, shading of PRIMARY iterations, [6] [7] [8] of BOUNCE iterations, [15] all;
 // lanes: [16] BOUNCE segments ending on the sky, [17] [18] [19] hitting a Lambertian / metal / dielectric sphere,
-// [20] rejection-loop trips summed over lanes, [21] [22] PRIMARY rays missing / hitting, [23] lanes taking a pooled path
+// [20] lanes still looking for a unit-ball point, summed over those passes, [21] [22] PRIMARY rays missing / hitting, [23] lanes taking a pooled path
 __device__ unsigned long long g_prof[32];
 
 // wave-local accumulation (values are wave-uniform), flushed once when the wave retires
@@ -208,6 +208,64 @@ static __device__ __forceinline__ void lds_order() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// randomInUnitSphere (basetypes.nim:114-118) for the lanes of a wave that need it (`need`), worked on by all 64.
+// A lane's rejection loop is a search for the first accepted trip t = 0, 1, ... of its stream, trip t
+// using draws 3t .. 3t+2 from the stream's position; any lane can evaluate any trip of any stream.  Left to
+// themselves the lanes run as many passes as the unluckiest of them (5.3 with 26 owners, of which one in
+// seven lanes does useful work); here the owners put their streams into LDS and the 64 lanes try T trips
+// for each of them at once (T = the power of two that fits, 64 / owners), the owner takes the first
+// accepted one from the lane that found it and advances its stream past exactly the trips the sequential
+// loop would have used - so the result is the sequential loop's, bit for bit.
+// Must be called by all 64 lanes together.  `slots`: 64 x 8 bytes of this wave's LDS, free at this point.
+static __device__ __forceinline__ void unit_ball_wave(bool need, Stream& g, f3& b, float& l2, uint32_t lane, uint2* slots RTOW_PROF_PARAM) {
+  constexpr uint32_t kTrip = 3u * kGolden;   // a trip is three draws
+  b = {0.0f, 0.0f, 0.0f};
+  l2 = 0.0f;
+  uint64_t m = __ballot(need);
+  while (m != 0) {
+    const uint32_t n = (uint32_t)__popcll(m);
+    RTOW_COUNT(11, 1);
+    RTOW_COUNT(20, n);
+    if (n > 32u) {
+      // more owners than half the wave: each runs one trip of its own
+      if (need) {
+        f3 p;
+        p.x = draw_pm1(g); p.y = draw_pm1(g); p.z = draw_pm1(g);
+        const float lp = dot3(p, p);
+        if (lp < 1.0f) { b = p; l2 = lp; need = false; }
+      }
+    } else {
+      const uint32_t cl = 32u - (uint32_t)__clz((int)(n - 1u));   // ceil(log2 n)
+      const uint32_t sh = cl == 0u ? 5u : 6u - cl;                // T = 32, 32, 16, 8, 4, 2 for n = 1, 2, <= 4, <= 8, <= 16, <= 32
+      const uint32_t T = 1u << sh;
+      const uint32_t r = lanes_below(m);                           // an owner's rank among the owners
+      if (need) slots[r] = make_uint2(g.x0, g.key1);
+      lds_order();
+      const uint32_t q = lane >> sh;                               // the owner this lane works for
+      const uint2 os = slots[q];
+      Stream h = {os.x + (lane & (T - 1u)) * kTrip, os.y};
+      f3 p;
+      p.x = draw_pm1(h); p.y = draw_pm1(h); p.z = draw_pm1(h);
+      const float lp = dot3(p, p);
+      const uint64_t acc = __ballot(q < n && lp < 1.0f);
+      const uint32_t mine = (uint32_t)(acc >> ((r << sh) & 63u)) & (0xffffffffu >> (32u - T));   // trips r*T .. r*T+T-1
+      const bool found = need && mine != 0u;
+      const uint32_t k = found ? (uint32_t)__builtin_ctz(mine) : 0u;
+      const int src = (int)((((r << sh) + k) & 63u) << 2);
+      const float fx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p.x)));
+      const float fy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p.y)));
+      const float fz = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, p.z)));
+      const float fl = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, lp)));
+      if (need) {
+        g.x0 += (found ? k + 1u : T) * kTrip;
+        if (found) { b = {fx, fy, fz}; l2 = fl; need = false; }
+      }
+      lds_order();
+    }
+    m = __ballot(need);
+  }
 }
 
 // wave-uniform control flow; `pass` differs per lane
@@ -697,7 +755,6 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     const unsigned long long t_seg = RTOW_CLOCK();
 
 #ifdef RTOW_PROFILE_COUNTERS
-    uint32_t shade_draws = 0;
     int shade_kind = -2;   // -2 no segment, -1 sky, else the material kind
 #endif
 #if defined(RTOW_PROFILE_COUNTERS) || defined(RTOW_PROFILE_TIMELINE)
@@ -797,9 +854,15 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       bool sky = false, cont = false;
       f3 p = {0, 0, 0}, dn = {0, 0, 1};
       float ptr_ = 1.0f, ptg_ = 1.0f, ptb_ = 1.0f;
+      const bool struck = gen && pid >= 0 && RTOW_GUARDED(4, pid, P.n_list);
+      f3 ball;
+      float ball_l2;
+      bool wants_ball = false;   // Lambertian and Metal scatter through randomInUnitSphere (hitrecord.nim:84,97)
+      if (struck) wants_ball = P.shade[pid].kind != kDielectric;
+      unit_ball_wave(wants_ball, g2, ball, ball_l2, lane, (uint2*)cand.list RTOW_PROF_ARG);
       if (gen) {
         if (P.hit_id && sample + P.sample_base == 0u && RTOW_GUARDED(3, pix2, (long long)P.n_rows * P.W)) P.hit_id[pix2] = pid;
-        if (pid < 0 || !RTOW_GUARDED(4, pid, P.n_list)) {
+        if (!struck) {
           // unitVector(r.dir).y = dir.y / length(dir); t = 0.5 (y + 1); (1 - t) * 1 + t * colour
           const double uy = dy / sqrt(dx * dx + dy * dy + dz * dz);
           const double ts = 0.5 * (uy + 1.0);
@@ -815,7 +878,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           float tmin_unused;
           segment_begin(sd, su, tmin_unused);
           const SphereShade sh = P.shade[pid];
-          cont = shade_at(sh, p, su, g2, dn, ptr_, ptg_, ptb_) && P.max_depth > 1;
+          cont = shade_at_ball(sh, p, su, g2, ball, ball_l2, dn, ptr_, ptg_, ptb_) && P.max_depth > 1;
         }
       }
       RTOW_COUNT(21, __popcll(__ballot(sky)));
@@ -867,14 +930,20 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       // A path that ends adds its radiance to its pixel right away, through the wave's cache of pixel sums
       // (paths that end absorbed or at the depth limit are black and add nothing).
       uint32_t fr = 0, fg = 0, fb = 0;
+      // world.hit + scatter (raytracer.nim:11-16)
+      const unsigned long long key = cand.best[lane];
+      const float best = __uint_as_float((uint32_t)(key >> 32));
+      const int id = hit_key_id(key);
+      const bool struck = alive && id >= 0 && RTOW_GUARDED(5, id, P.n_list);
+      f3 ball;
+      float ball_l2;
+      bool wants_ball = false;   // Lambertian and Metal scatter through randomInUnitSphere (hitrecord.nim:84,97)
+      if (struck) wants_ball = P.shade[id].kind != kDielectric;
+      unit_ball_wave(wants_ball, g, ball, ball_l2, lane, (uint2*)cand.list RTOW_PROF_ARG);
       if (alive) {
-        // world.hit + scatter (raytracer.nim:11-16)
-        const unsigned long long key = cand.best[lane];
-        const float best = __uint_as_float((uint32_t)(key >> 32));
-        const int id = hit_key_id(key);
         float rr_ = 0.0f, rg_ = 0.0f, rb_ = 0.0f;
         bool ended;
-        if (id < 0 || !RTOW_GUARDED(5, id, P.n_list)) {
+        if (!struck) {
           shade_sky(u, tr, tg, tb, rr_, rg_, rb_);
           ended = true;
 #ifdef RTOW_PROFILE_COUNTERS
@@ -883,12 +952,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         } else {
           const SphereShade sh = P.shade[id];
           f3 dn;
+          const f3 p = {fmaf(best, u.x, o.x), fmaf(best, u.y, o.y), fmaf(best, u.z, o.z)};
+          o = p;   // the scattered ray starts at the hit point whether or not it survives
+          const bool scattered = shade_at_ball(sh, p, u, g, ball, ball_l2, dn, tr, tg, tb);
 #ifdef RTOW_PROFILE_COUNTERS
-          const uint32_t x0_before = g.x0;
-#endif
-          const bool scattered = shade_hit(sh, o, u, best, g, dn, tr, tg, tb);
-#ifdef RTOW_PROFILE_COUNTERS
-          shade_draws = (g.x0 - x0_before) * 0x144cbc89u;
           shade_kind = sh.kind;
 #endif
           d = dn;
@@ -906,16 +973,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     RTOW_COUNT(3, 1);
 #ifdef RTOW_PROFILE_COUNTERS
     {
-      uint32_t m_ = shade_draws;
-      for (int off = 32; off > 0; off >>= 1) { const uint32_t t_ = __shfl_xor(m_, off, 64); m_ = t_ > m_ ? t_ : m_; }
-      RTOW_COUNT(11, m_ / 3u);   // rejection-loop trips of the slowest lane
       RTOW_COUNT(16, __popcll(__ballot(shade_kind == -1)));
       RTOW_COUNT(17, __popcll(__ballot(shade_kind == kLambertian)));
       RTOW_COUNT(18, __popcll(__ballot(shade_kind == kMetal)));
       RTOW_COUNT(19, __popcll(__ballot(shade_kind == kDielectric)));
-      uint32_t t_ = (shade_kind == kLambertian || shade_kind == kMetal) ? shade_draws / 3u : 0u;
-      for (int off = 32; off > 0; off >>= 1) t_ += __shfl_xor(t_, off, 64);
-      RTOW_COUNT(20, t_);
     }
 #endif
 #ifdef RTOW_PROFILE_TIMELINE

@@ -277,7 +277,10 @@ RTOW_HD void shade_sky(f3 u, float tr, float tg, float tb, float& rr, float& rg,
 // Updates origin, direction and throughput; returns false when the path is absorbed (Metal
 // scattering below the surface, hitrecord.nim:99), in which case it contributes black.
 // shade_at: the same at a hit point p that the caller has already computed.
-RTOW_HD bool shade_at(const SphereShade& s, f3 p, f3 u, Stream& g, f3& d_next, float& tr, float& tg, float& tb) {
+// shade_at_ball: the same with the point of randomInUnitSphere (b, |b|^2 = l2) already drawn from g by the
+// caller; a dielectric ignores it (and must not have had it drawn).
+RTOW_HD bool shade_at_ball(const SphereShade& s, f3 p, f3 u, Stream& g, f3 b, float l2, f3& d_next,
+                           float& tr, float& tg, float& tb) {
   f3 n = {(p.x - s.cx) * s.inv_r, (p.y - s.cy) * s.inv_r, (p.z - s.cz) * s.inv_r};
   const bool front = dot3(u, n) < 0.0f;  // setFaceNormal, hitrecord.nim:51-53
   if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
@@ -306,8 +309,6 @@ RTOW_HD bool shade_at(const SphereShade& s, f3 p, f3 u, Stream& g, f3& d_next, f
       nd.x = fmaf(par, n.x, perp.x); nd.y = fmaf(par, n.y, perp.y); nd.z = fmaf(par, n.z, perp.z);
     }
   } else {
-    float l2;
-    const f3 b = unit_ball(g, l2);
     if (s.kind == kLambertian) {  // hitrecord.nim:82-92
       const float ib = rt_rcp(rt_sqrt(l2));
       nd.x = fmaf(b.x, ib, n.x); nd.y = fmaf(b.y, ib, n.y); nd.z = fmaf(b.z, ib, n.z);
@@ -323,6 +324,13 @@ RTOW_HD bool shade_at(const SphereShade& s, f3 p, f3 u, Stream& g, f3& d_next, f
   }
   d_next = nd;
   return true;
+}
+
+RTOW_HD bool shade_at(const SphereShade& s, f3 p, f3 u, Stream& g, f3& d_next, float& tr, float& tg, float& tb) {
+  f3 b = {0.0f, 0.0f, 0.0f};
+  float l2 = 0.0f;
+  if (s.kind != kDielectric) b = unit_ball(g, l2);
+  return shade_at_ball(s, p, u, g, b, l2, d_next, tr, tg, tb);
 }
 
 RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3& d_next,

@@ -22,7 +22,7 @@ print(f"cycles per iteration: all {b[15]/it:.0f};  hand-out {b[5]/it:.0f}")
 print(f"  PRIMARY {(b[1]+b[2]+b[13])/prim:.0f} = set-up {b[1]/prim:.0f} + scan {b[2]/prim:.0f} + shading {b[13]/prim:.0f}")
 print(f"  BOUNCE  {(b[6]+b[7]+b[8])/bounce:.0f} = set-up {b[6]/bounce:.0f} + scan {b[7]/bounce:.0f} + shading {b[8]/bounce:.0f}")
 print(f"per iteration: groups with a survivor {b[9]/it:.2f}, exact-test rounds binary32 {b[10]/bounce:.2f} per BOUNCE, binary64 {b[12]/prim:.2f} per PRIMARY, "
-      f"unit-ball trips of the slowest lane {b[11]/bounce:.2f} per BOUNCE")
+      f"unit-ball passes {b[11]/it:.2f}")
 print(f"pixel-sum cache: {b[0]} slots written to the frame = {b[0]/it:.3f} per iteration, {b[0]/(1200*800):.2f} per pixel, {b[0]*192/1e6:.0f} MB of 64-byte atomics")
 # lane utilisation of the phases outside the scan (lanes at work / 64, per iteration of that kind)
 print(f"hand-out: {b[23]/(64*bounce):.3f} of lanes take a pooled path per BOUNCE iteration")
@@ -30,5 +30,4 @@ print(f"PRIMARY shading: sky {b[21]/(64*prim):.3f}, hit (scatter) {b[22]/(64*pri
 print(f"BOUNCE shading: sky {b[16]/(64*bounce):.3f}, Lambertian {b[17]/(64*bounce):.3f}, metal {b[18]/(64*bounce):.3f}, "
       f"dielectric {b[19]/(64*bounce):.3f} of lanes")
 if b[11]:
-    print(f"unit-ball loop: {b[20]/(b[17]+b[18]):.2f} trips per lane that runs it, {b[11]/bounce:.2f} passes per iteration "
-          f"=> {b[20]/(64*b[11]):.3f} of lanes at work per pass")
+    print(f"unit-ball search: {b[11]/it:.2f} passes per iteration (both kinds), {b[20]/b[11]:.1f} lanes looking per pass")
