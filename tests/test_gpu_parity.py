@@ -432,6 +432,24 @@ def test_full_size_properties(gpu_renderer, oracle, book_scene):
     assert acc.max() <= spp * 2 ** 30
 
 
+@pytest.mark.parametrize("variant", [{}, {"lambert_below": 0.0, "metal_below": 0.5}])
+def test_headline_frame_whole_bit_exact_at_low_spp(oracle, variant):
+    """The whole 1200x800 frame of the headline config, depth 50, at 6 samples per pixel (the CPU mirror
+    takes about a second on 16 threads): every hit id, 64-bit sum and pixel, and the segment count.  Once on
+    the book scene, once with every small sphere metal or glass."""
+    R = _R()
+    arr, n, _, _ = oracle.random_scene(**variant)
+    host = R.randomScene(**({"lambertBelow": 0.0, "metalBelow": 0.5} if variant else {}))
+    W, H, spp, depth = 1200, 800, 6, 50
+    with R.Renderer(0) as r:
+        r.setWorld(host)
+        r.setCamera(R.bookCamera(W / H))
+        got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+        ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, spp, depth, threads=16)
+        _check_bit_exact(got, ref)
+        assert r.stats()["ray_segments"] == ref[3]
+
+
 def test_async_device_resident_render(gpu_renderer):
     import torch
     R = _R()
