@@ -59,7 +59,7 @@ def hbm_traffic(workload, spp, world):
 def cpu_baseline(width, height, depth, seed):
     """Time the FP64 restatement of the reference on a bounded sample: 16 rows spread over the
     frame.  Single thread first (the reference is single-threaded), then all host cores.  Also the
-    reference's own CPU-sized case in full: 400x225, spp 10, depth 50 (BASELINE config 1), one thread."""
+    reference's own CPU-sized case in full: 400x225, spp 10, depth 50 (the first of the benchmark configurations), one thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     arr, n, _, _ = O.random_scene()

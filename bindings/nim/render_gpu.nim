@@ -2,7 +2,7 @@
 ##   render*    raytracer.nim:30-32   (the triple loop replaced by one call; `seed` added, defaulted)
 ##   rayColor*  raytracer.nim:5       hit*  hittables.nim:79       getRay*  camera.nim:34
 ## `flatten` (Camera -> RtowCameraF64) must live in camera.nim because Camera's fields are private
-## (camera.nim:5-10); see INTEGRATION.md.  Import this module INSTEAD of the reference's own definitions
+## (camera.nim:5-10): it copies the eight fields, in declaration order.  Import this module INSTEAD of the reference's own definitions
 ## of these four procs.  Unverified in the build image (no Nim toolchain there).
 import basetypes, hittables, camera, hitrecord, rtow_abi
 

@@ -226,7 +226,7 @@ def test_converged_frame_against_reference_png_thumbnail(gpu_renderer):
 
 
 def test_ten_thousand_spheres(oracle):
-    """BASELINE config 5's scene: randomScene with a 101 x 101 grid (10 001 spheres in the linear list; the
+    """The largest benchmark configuration's scene: randomScene with a 101 x 101 grid (10 001 spheres in the linear list; the
     table streams through scalar registers, nothing of it fits LDS).  A small frame bit-exact against the
     CPU mirror, then the 3840 x 2160 frame at one sample per pixel through size-independent properties:
     path and segment counts, sky rows, hit ids in range, a band of rows equal to the mirror's."""
