@@ -91,8 +91,8 @@ def cpu_baseline(width, height, depth, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline number)")
     ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (contexts used in turn); 1 = strictly serial steps")
