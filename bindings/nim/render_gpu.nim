@@ -1,9 +1,9 @@
 ## Drop-in bodies for the procs of the hot path, same names and parameter lists as the reference:
 ##   render*    raytracer.nim:30-32   (the triple loop replaced by one call; `seed` added, defaulted)
-##   rayColor*  raytracer.nim:5       hit*  hittables.nim:79       getRay*  camera.nim:34
+##   rayColor*  raytracer.nim:5       hit*  hittables.nim:79       getRay*  camera.nim:34       scatter*  hitrecord.nim:127
 ## `flatten` (Camera -> RtowCameraF64) must live in camera.nim because Camera's fields are private
 ## (camera.nim:5-10): it copies the eight fields, in declaration order.  Import this module INSTEAD of the reference's own definitions
-## of these four procs.  Unverified in the build image (no Nim toolchain there).
+## of these five procs.  Unverified in the build image (no Nim toolchain there).
 import basetypes, hittables, camera, hitrecord, rtow_abi
 
 proc check(status: cint, what: string) =
@@ -92,6 +92,30 @@ proc hit*(h: var HittablesList, r: Ray, t_min, t_max: float, rec: var HitRecord)
   rec.setFaceNormal(r, (rec.p - s.center) / s.radius)      # hitrecord.nim:73-77
   rec.mat = s.mat
   true
+
+proc scatter*(m: Material, r_in: Ray, rec: HitRecord, attenuation: var Color, scattered: var Ray): bool =
+  ## hitrecord.nim:127-132; draws from the stream of path (pixel 0, sample 0) instead of the global generator
+  let ctx = device()
+  var d = [r_in.dir.x, r_in.dir.y, r_in.dir.z]
+  var n = [rec.normal.x, rec.normal.y, rec.normal.z]
+  var front = (if rec.frontFace: 1'u8 else: 0'u8)
+  var kind = m.kind.ord.uint8
+  var albedo = [1.0, 1.0, 1.0]
+  var fuzz = 0.0
+  var ir = 1.0
+  case m.kind
+  of mkLambertian: albedo = [m.mLambertian.albedo.r, m.mLambertian.albedo.g, m.mLambertian.albedo.b]
+  of mkMetal:
+    albedo = [m.mMetal.albedo.r, m.mMetal.albedo.g, m.mMetal.albedo.b]
+    fuzz = m.mMetal.fuzz
+  of mkDielectric: ir = m.mDielectric.ir
+  var att, sd: array[3, cdouble]
+  var ok: uint8
+  check rtow_scatter_rays(ctx, 1, addr d[0], addr n[0], addr front, addr kind, addr albedo[0], addr fuzz, addr ir,
+                          0xE7'u64, addr att[0], addr sd[0], addr ok), "rtow_scatter_rays"
+  attenuation = color(att[0], att[1], att[2])
+  scattered = initRay(rec.p, vec3(sd[0], sd[1], sd[2]))
+  ok != 0
 
 proc getRay*(c: Camera, s, t: float): Ray =
   let ctx = device()

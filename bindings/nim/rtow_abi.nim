@@ -30,6 +30,9 @@ proc rtow_trace_rays*(ctx: RtowCtx, n: cint, origins, directions: ptr cdouble, t
                       seed: uint64, colorOut: ptr cdouble, hitIdOut: ptr int32, tOut: ptr cdouble): cint {.importc, dynlib: rtowLib.}
 proc rtow_get_rays*(ctx: RtowCtx, n: cint, s, t: ptr cdouble, seed: uint64,
                     originsOut, directionsOut: ptr cdouble): cint {.importc, dynlib: rtowLib.}
+proc rtow_scatter_rays*(ctx: RtowCtx, n: cint, directions, normals: ptr cdouble, frontFace, kind: ptr uint8,
+                        albedoRgb, fuzz, ir: ptr cdouble, seed: uint64, attenuationOut, scatteredDirOut: ptr cdouble,
+                        scatteredOut: ptr uint8): cint {.importc, dynlib: rtowLib.}
 proc rtow_read_image*(ctx: RtowCtx, rgb: ptr uint8, accum: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_format_ppm*(ctx: RtowCtx, binary: cint, dst: cstring, capacity: uint64, length: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_selftest_arithmetic*(ctx: RtowCtx, mismatches: ptr uint64): cint {.importc, dynlib: rtowLib.}

@@ -202,6 +202,25 @@ int rtow_trace_rays(rtow_ctx* ctx, int n, const double* origins, const double* d
 int rtow_get_rays(rtow_ctx* ctx, int n, const double* s, const double* t, uint64_t seed,
                   double* origins_out, double* directions_out);
 
+/* scatter*(m, r_in, rec, attenuation, scattered): bool (hitrecord.nim:127-132 over :82-125) for n independent
+ * (material, incoming ray, hit record) triples.  In: directions (n*3, r_in.dir, not normalised), normals
+ * (n*3, rec.normal: unit, already turned against the ray by setFaceNormal, hitrecord.nim:51-53),
+ * front_face (n, rec.frontFace), and the material as rtow_set_scene takes it (kind, albedo_rgb n*3 - ignored
+ * for a dielectric - fuzz, ir).  Out: attenuation_out (n*3), scattered_dir_out (n*3, scattered.dir, not
+ * normalised; scattered.orig is rec.p, which the caller has) and scattered_out (n, the proc's result; 0
+ * only for a Metal whose fuzzed reflection points below the surface, hitrecord.nim:99 - direction and
+ * attenuation are delivered all the same, as the reference's var parameters are).
+ * The arithmetic is the renderer's scatter: binary32 on the rounded inputs, with the unit direction of
+ * r_in (the reference normalises it where Metal and Dielectric use it, hitrecord.nim:96,112).  Triple i
+ * draws from the stream of path (pixel i, sample 0) of `seed`, from that stream's first draw: three per
+ * trip of randomInUnitSphere (basetypes.nim:114-118) for Lambertian and Metal, one for a Dielectric that
+ * can refract (hitrecord.nim:119).  Needs neither scene nor camera.  Host pointers; blocks until the
+ * results are there; n at most 2^27. */
+int rtow_scatter_rays(rtow_ctx* ctx, int n, const double* directions, const double* normals,
+                      const uint8_t* front_face, const uint8_t* kind, const double* albedo_rgb,
+                      const double* fuzz, const double* ir, uint64_t seed, double* attenuation_out,
+                      double* scattered_dir_out, uint8_t* scattered_out);
+
 /* One frame on several contexts at once - normally one context per GPU of this process, each
  * holding the same scene and camera.  The rows of the image - the outer j loop of render
  * (raytracer.nim:36) - are dealt to the contexts in interleaved tiles of tile_rows rows (tile t goes

@@ -287,6 +287,56 @@ static inline uint64_t to_fix(float c) {
   return (uint64_t)(uint32_t)(c * FIX_ONE);
 }
 
+/* scatter (hitrecord.nim:82-132) in binary32: n is the face-set unit normal, front the frontFace flag, u the
+ * unit direction of the incoming ray.  Sets the next direction and multiplies the throughput by the
+ * attenuation - also when it returns 0 (Metal scattering below the surface, hitrecord.nim:99). */
+static int scatter32(const sph32* s, f3 n, int front, f3 u, stream* g, f3* nd_out, float* tr, float* tg, float* tb) {
+  f3 nd;
+  int ok = 1;
+  if (s->kind == ORC_DIELECTRIC) { /* hitrecord.nim:107-125 */
+    const float ratio = front ? s->inv_ir : s->ir;
+    const float dn = dot3(u, n);
+    const float cos_t = fminf(-dn, 1.0f);
+    const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+    int reflect_it = ratio * sin_t > 1.0f;
+    if (!reflect_it) {
+      float r0 = (1.0f - ratio) / (1.0f + ratio);
+      r0 = r0 * r0;
+      const float x = 1.0f - cos_t;
+      const float x2 = x * x;
+      const float x5 = x2 * x2 * x;
+      const float refl = fmaf(1.0f - r0, x5, r0);
+      reflect_it = refl > draw(g);
+    }
+    if (reflect_it) {
+      const float k2 = -2.0f * dn;
+      nd.x = fmaf(k2, n.x, u.x); nd.y = fmaf(k2, n.y, u.y); nd.z = fmaf(k2, n.z, u.z);
+    } else {
+      f3 perp = {ratio * fmaf(cos_t, n.x, u.x), ratio * fmaf(cos_t, n.y, u.y), ratio * fmaf(cos_t, n.z, u.z)};
+      const float par = -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+      nd.x = fmaf(par, n.x, perp.x); nd.y = fmaf(par, n.y, perp.y); nd.z = fmaf(par, n.z, perp.z);
+    }
+    /* attenuation is white */
+  } else {
+    float l2;
+    const f3 b = unit_ball(g, &l2);
+    if (s->kind == ORC_LAMBERTIAN) { /* hitrecord.nim:82-92 */
+      const float ib = 1.0f / sqrtf(l2);
+      nd.x = fmaf(b.x, ib, n.x); nd.y = fmaf(b.y, ib, n.y); nd.z = fmaf(b.z, ib, n.z);
+      if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
+    } else { /* Metal, hitrecord.nim:94-99 */
+      const float k2 = -2.0f * dot3(u, n);
+      nd.x = fmaf(s->fuzz, b.x, fmaf(k2, n.x, u.x));
+      nd.y = fmaf(s->fuzz, b.y, fmaf(k2, n.y, u.y));
+      nd.z = fmaf(s->fuzz, b.z, fmaf(k2, n.z, u.z));
+      ok = dot3(nd, n) > 0.0f;
+    }
+    *tr *= s->ar; *tg *= s->ag; *tb *= s->ab;
+  }
+  *nd_out = nd;
+  return ok;
+}
+
 /* rayColor (raytracer.nim:5-20) for one ray given in binary64: the first world.hit in binary64 over
  * [t_min, t_max], every later segment in binary32.  colour: binary64 sky colour for a first-segment miss,
  * otherwise the binary32 radiance of the path (widened); returns 1 when the colour is such a binary64 sky
@@ -348,46 +398,7 @@ static int trace_ray(const job32* jb, const double o64[3], const double d64[3], 
     const int front = dot3(u, n) < 0.0f;
     if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
     f3 nd; /* next direction */
-    if (s->kind == ORC_DIELECTRIC) { /* hitrecord.nim:107-125 */
-      const float ratio = front ? s->inv_ir : s->ir;
-      const float dn = dot3(u, n);
-      const float cos_t = fminf(-dn, 1.0f);
-      const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
-      int reflect_it = ratio * sin_t > 1.0f;
-      if (!reflect_it) {
-        float r0 = (1.0f - ratio) / (1.0f + ratio);
-        r0 = r0 * r0;
-        const float x = 1.0f - cos_t;
-        const float x2 = x * x;
-        const float x5 = x2 * x2 * x;
-        const float refl = fmaf(1.0f - r0, x5, r0);
-        reflect_it = refl > draw(&g);
-      }
-      if (reflect_it) {
-        const float k2 = -2.0f * dn;
-        nd.x = fmaf(k2, n.x, u.x); nd.y = fmaf(k2, n.y, u.y); nd.z = fmaf(k2, n.z, u.z);
-      } else {
-        f3 perp = {ratio * fmaf(cos_t, n.x, u.x), ratio * fmaf(cos_t, n.y, u.y), ratio * fmaf(cos_t, n.z, u.z)};
-        const float par = -sqrtf(fabsf(1.0f - dot3(perp, perp)));
-        nd.x = fmaf(par, n.x, perp.x); nd.y = fmaf(par, n.y, perp.y); nd.z = fmaf(par, n.z, perp.z);
-      }
-      /* attenuation is white */
-    } else {
-      float l2;
-      const f3 b = unit_ball(&g, &l2);
-      if (s->kind == ORC_LAMBERTIAN) { /* hitrecord.nim:82-92 */
-        const float ib = 1.0f / sqrtf(l2);
-        nd.x = fmaf(b.x, ib, n.x); nd.y = fmaf(b.y, ib, n.y); nd.z = fmaf(b.z, ib, n.z);
-        if (fabsf(nd.x) < 1e-8f && fabsf(nd.y) < 1e-8f && fabsf(nd.z) < 1e-8f) nd = n;
-      } else { /* Metal, hitrecord.nim:94-99 */
-        const float k2 = -2.0f * dot3(u, n);
-        nd.x = fmaf(s->fuzz, b.x, fmaf(k2, n.x, u.x));
-        nd.y = fmaf(s->fuzz, b.y, fmaf(k2, n.y, u.y));
-        nd.z = fmaf(s->fuzz, b.z, fmaf(k2, n.z, u.z));
-        if (!(dot3(nd, n) > 0.0f)) break; /* absorbed: black */
-      }
-      tr *= s->ar; tg *= s->ag; tb *= s->ab;
-    }
+    if (!scatter32(s, n, front, u, &g, &nd, &tr, &tg, &tb)) break; /* absorbed: black */
     o = p;
     d = nd;
     prev = id;
@@ -541,4 +552,26 @@ int orc_mirror32_trace_ray(const orc_sphere* spheres, int n_spheres, const doubl
   if (t) *t = t64;
   free(w);
   return first;
+}
+
+/* scatter for one (material, incoming ray, hit record) triple in the device's arithmetic: inputs rounded to
+ * binary32, the direction normalised first; draws from the stream of path (pixel index, sample 0) */
+int orc_mirror32_scatter(const orc_sphere* material, const double in_dir[3], const double normal[3], int front_face,
+                         uint64_t seed, uint32_t index, double attenuation[3], double out_dir[3]) {
+  sph32 w;
+  float cmax;
+  prep_scene(material, 1, &w, &cmax);
+  const f3 d = {(float)in_dir[0], (float)in_dir[1], (float)in_dir[2]};
+  const f3 n = {(float)normal[0], (float)normal[1], (float)normal[2]};
+  const float il = 1.0f / sqrtf(dot3(d, d));
+  const f3 u = {d.x * il, d.y * il, d.z * il};
+  stream g;
+  orc_path_key(seed, index, 0u, g.key);
+  g.k = 0;
+  float tr = 1.0f, tg = 1.0f, tb = 1.0f;
+  f3 nd;
+  const int ok = scatter32(&w, n, front_face != 0, u, &g, &nd, &tr, &tg, &tb);
+  attenuation[0] = tr; attenuation[1] = tg; attenuation[2] = tb;
+  out_dir[0] = nd.x; out_dir[1] = nd.y; out_dir[2] = nd.z;
+  return ok;
 }

@@ -146,6 +146,10 @@ void orc_ref64_ray_color(const orc_sphere* spheres, int n, const double orig[3],
 int orc_mirror32_trace_ray(const orc_sphere* spheres, int n_spheres, const double orig[3], const double dir[3],
                            double t_min, double t_max, int max_depth, uint64_t seed, uint32_t index, double colour[3],
                            double* t);
+/* scatter (hitrecord.nim:127-132) for one triple in the device's binary32 arithmetic (material = the
+ * material fields of *material; its centre and radius are not used) */
+int orc_mirror32_scatter(const orc_sphere* material, const double in_dir[3], const double normal[3], int front_face,
+                         uint64_t seed, uint32_t index, double attenuation[3], double out_dir[3]);
 /* writeColor quantisation of one channel sum (raytracer.nim:22-28) */
 int orc_ref64_quantise(double channel_sum, int spp);
 

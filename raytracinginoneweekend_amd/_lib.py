@@ -44,7 +44,7 @@ class Stats(C.Structure):
 # every symbol include/rtow.h declares
 SYMBOLS = ["rtow_last_error", "rtow_version", "rtow_device_count", "rtow_create", "rtow_destroy",
            "rtow_set_scene", "rtow_set_scene_f64", "rtow_set_camera", "rtow_set_camera_f64", "rtow_render", "rtow_render_async", "rtow_sync",
-           "rtow_render_multi", "rtow_trace_rays", "rtow_get_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
+           "rtow_render_multi", "rtow_trace_rays", "rtow_get_rays", "rtow_scatter_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
 
 _lib = None
 
@@ -123,6 +123,7 @@ def load(path, strict=True):
     L.rtow_render_noalloc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp]
     L.rtow_trace_rays.argtypes = [vp, C.c_int, vp, vp, C.c_double, C.c_double, C.c_int, C.c_uint64, vp, vp, vp]
     L.rtow_get_rays.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, vp, vp]
+    L.rtow_scatter_rays.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     L.rtow_read_image.argtypes = [vp, vp, vp]
     L.rtow_format_ppm.argtypes = [vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.rtow_selftest_arithmetic.argtypes = [vp, C.POINTER(C.c_uint64)]

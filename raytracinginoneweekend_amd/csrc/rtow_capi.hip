@@ -922,6 +922,51 @@ int rtow_get_rays(rtow_ctx* c, int n, const double* s, const double* t, uint64_t
   return run_rays(c, "rtow_get_rays", true, n, s, t, 1, 0.0, 0.0, 0, seed, origins_out, nullptr, directions_out, 3);
 }
 
+int rtow_scatter_rays(rtow_ctx* c, int n, const double* directions, const double* normals, const uint8_t* front_face,
+                      const uint8_t* kind, const double* albedo_rgb, const double* fuzz, const double* ir, uint64_t seed,
+                      double* attenuation_out, double* scattered_dir_out, uint8_t* scattered_out) {
+  if (!c) return fail(RTOW_ERR_INVALID, "rtow_scatter_rays: ctx is NULL");
+  if (n < 0 || (n > 0 && (!directions || !normals || !front_face || !kind || !albedo_rgb || !fuzz || !ir ||
+                          !attenuation_out || !scattered_dir_out || !scattered_out)))
+    return fail(RTOW_ERR_INVALID, "rtow_scatter_rays: n = %d or NULL array", n);
+  if (n > (1 << 27)) return fail(RTOW_ERR_INVALID, "rtow_scatter_rays: n = %d triples in one call (at most 2^27)", n);
+  for (int i = 0; i < n; ++i) {
+    if (kind[i] > RTOW_DIELECTRIC) return fail(RTOW_ERR_INVALID, "rtow_scatter_rays: material %d has unknown kind %d", i, (int)kind[i]);
+    if (kind[i] == RTOW_DIELECTRIC && !(std::isfinite(ir[i]) && ir[i] > 0.0))
+      return fail(RTOW_ERR_INVALID, "rtow_scatter_rays: material %d: refraction index %g", i, ir[i]);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->pending) { const int rc = rtow_sync(c); if (rc != RTOW_OK) return rc; }
+  if (n == 0) return RTOW_OK;
+  // device layout: [dir 3n | normal 3n | albedo 3n | fuzz n | ir n] doubles, then [front n | kind n] bytes
+  const size_t N = (size_t)n, d3 = sizeof(double) * 3 * N, d1 = sizeof(double) * N;
+  HIP_TRY(c->ray_in.reserve(3 * d3 + 2 * d1 + 2 * N));
+  HIP_TRY(c->ray_out.reserve(2 * d3 + N));
+  char* in = (char*)c->ray_in.p;
+  char* out = (char*)c->ray_out.p;
+  const void* src[7] = {directions, normals, albedo_rgb, fuzz, ir, front_face, kind};
+  const size_t len[7] = {d3, d3, d3, d1, d1, N, N};
+  size_t off[7], at = 0;
+  for (int k = 0; k < 7; ++k) {
+    off[k] = at;
+    HIP_TRY(hipMemcpyAsync(in + at, src[k], len[k], hipMemcpyHostToDevice, c->stream));
+    at += len[k];
+  }
+  rtow::ScatterParams p;
+  p.n = n; p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+  p.dir = (const double*)(in + off[0]); p.normal = (const double*)(in + off[1]); p.albedo = (const double*)(in + off[2]);
+  p.fuzz = (const double*)(in + off[3]); p.ir = (const double*)(in + off[4]);
+  p.front = (const uint8_t*)(in + off[5]); p.kind = (const uint8_t*)(in + off[6]);
+  p.attenuation = (double*)out; p.out_dir = (double*)(out + d3); p.ok = (uint8_t*)(out + 2 * d3);
+  rtow::launch_scatter(p, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(attenuation_out, p.attenuation, d3, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(scattered_dir_out, p.out_dir, d3, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(scattered_out, p.ok, N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOW_OK;
+}
+
 int rtow_selftest_arithmetic(rtow_ctx* c, uint64_t mismatches[2]) {
   if (!c || !mismatches) return fail(RTOW_ERR_INVALID, "rtow_selftest_arithmetic: NULL argument");
   HIP_TRY(hipSetDevice(c->device));

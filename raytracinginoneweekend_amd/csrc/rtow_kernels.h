@@ -63,6 +63,23 @@ struct RayParams {
 };
 void launch_rays(const RayParams& p, bool get_rays, hipStream_t stream);
 
+// scatter (hitrecord.nim:127-132) for n caller-given (material, incoming ray, hit record) triples
+struct ScatterParams {
+  int n;
+  uint32_t seed_lo, seed_hi;
+  const double* dir;         // n*3 r_in.dir (not normalised)
+  const double* normal;      // n*3 rec.normal (unit, already turned against the ray)
+  const uint8_t* front;      // n   rec.frontFace
+  const uint8_t* kind;       // n   material kind
+  const double* albedo;      // n*3 (ignored for a dielectric)
+  const double* fuzz;        // n
+  const double* ir;          // n
+  double* attenuation;       // n*3 out
+  double* out_dir;           // n*3 out: scattered.dir
+  uint8_t* ok;               // n   out: the proc's result
+};
+void launch_scatter(const ScatterParams& p, hipStream_t stream);
+
 void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);

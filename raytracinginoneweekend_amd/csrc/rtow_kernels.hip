@@ -1307,6 +1307,46 @@ __global__ void __launch_bounds__(256) rtow_get_rays_kernel(const RayParams P) {
   }
 }
 
+// scatter*(m, r_in, rec, attenuation, scattered) (hitrecord.nim:127-132) for n independent triples, in the
+// arithmetic the renderer scatters with: binary32 on the rounded inputs, the incoming direction normalised
+// first (Metal, Dielectric and the sky use the unit direction, hitrecord.nim:96,112).  Triple i draws from
+// the stream of path (pixel i, sample 0), starting at that stream's first draw.
+__global__ void __launch_bounds__(256) rtow_scatter_kernel(const ScatterParams P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const f3 d = {(float)P.dir[3 * i], (float)P.dir[3 * i + 1], (float)P.dir[3 * i + 2]};
+  const f3 n = {(float)P.normal[3 * i], (float)P.normal[3 * i + 1], (float)P.normal[3 * i + 2]};
+  f3 u;
+  float tmin_unused;
+  segment_begin(d, u, tmin_unused);
+  SphereShade s;
+  s.cx = s.cy = s.cz = 0.0f; s.inv_r = 1.0f; s.pad_ = 0.0f;
+  s.kind = (int32_t)P.kind[i];
+  s.fuzz = (float)P.fuzz[i];
+  s.ir = (float)P.ir[i];
+  s.inv_ir = 1.0f / s.ir;
+  if (s.kind == kDielectric) {   // a dielectric's record carries its two Schlick constants, attenuation is white
+    s.ar = schlick_r0(s.inv_ir); s.ag = schlick_r0(s.ir); s.ab = 1.0f;
+  } else {
+    s.ar = (float)P.albedo[3 * i]; s.ag = (float)P.albedo[3 * i + 1]; s.ab = (float)P.albedo[3 * i + 2];
+  }
+  Stream g = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)i, 0u);
+  f3 b = {0.0f, 0.0f, 0.0f};
+  float l2 = 0.0f;
+  if (s.kind != kDielectric) b = unit_ball(g, l2);
+  float tr = 1.0f, tg = 1.0f, tb = 1.0f;
+  f3 nd = {0.0f, 0.0f, 0.0f};
+  const bool ok = scatter_ball<true>(s, n, P.front[i] != 0, u, g, b, l2, nd, tr, tg, tb);
+  P.attenuation[3 * i] = tr; P.attenuation[3 * i + 1] = tg; P.attenuation[3 * i + 2] = tb;
+  P.out_dir[3 * i] = nd.x; P.out_dir[3 * i + 1] = nd.y; P.out_dir[3 * i + 2] = nd.z;
+  P.ok[i] = ok ? 1 : 0;
+}
+
+void launch_scatter(const ScatterParams& p, hipStream_t stream) {
+  if (p.n <= 0) return;
+  hipLaunchKernelGGL(rtow_scatter_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+}
+
 void launch_rays(const RayParams& p, bool get_rays, hipStream_t stream) {
   if (p.n <= 0) return;
   if (get_rays) hipLaunchKernelGGL(rtow_get_rays_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);

@@ -277,13 +277,14 @@ RTOW_HD void shade_sky(f3 u, float tr, float tg, float tb, float& rr, float& rg,
 // Updates origin, direction and throughput; returns false when the path is absorbed (Metal
 // scattering below the surface, hitrecord.nim:99), in which case it contributes black.
 // shade_at: the same at a hit point p that the caller has already computed.
-// shade_at_ball: the same with the point of randomInUnitSphere (b, |b|^2 = l2) already drawn from g by the
-// caller; a dielectric ignores it (and must not have had it drawn).
-RTOW_HD bool shade_at_ball(const SphereShade& s, f3 p, f3 u, Stream& g, f3 b, float l2, f3& d_next,
-                           float& tr, float& tg, float& tb) {
-  f3 n = {(p.x - s.cx) * s.inv_r, (p.y - s.cy) * s.inv_r, (p.z - s.cz) * s.inv_r};
-  const bool front = dot3(u, n) < 0.0f;  // setFaceNormal, hitrecord.nim:51-53
-  if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
+// scatter (hitrecord.nim:82-132) on the material of record s, given the face-set unit normal n, the frontFace
+// flag, the unit direction u of the incoming ray and - for Lambertian and Metal - the point of
+// randomInUnitSphere (b, |b|^2 = l2) already drawn from g.  Multiplies the throughput by the attenuation.
+// ALWAYS_OUT: also deliver direction and attenuation when the result is false (Metal scattering below the
+// surface, hitrecord.nim:99), as the reference's var parameters do; the path tracer has no use for them.
+template <bool ALWAYS_OUT>
+RTOW_HD bool scatter_ball(const SphereShade& s, f3 n, bool front, f3 u, Stream& g, f3 b, float l2, f3& d_next,
+                          float& tr, float& tg, float& tb) {
   f3 nd;
   if (s.kind == kDielectric) {  // hitrecord.nim:107-125
     const float ratio = front ? s.inv_ir : s.ir;
@@ -318,12 +319,25 @@ RTOW_HD bool shade_at_ball(const SphereShade& s, f3 p, f3 u, Stream& g, f3 b, fl
       nd.x = fmaf(s.fuzz, b.x, fmaf(k2, n.x, u.x));
       nd.y = fmaf(s.fuzz, b.y, fmaf(k2, n.y, u.y));
       nd.z = fmaf(s.fuzz, b.z, fmaf(k2, n.z, u.z));
-      if (!(dot3(nd, n) > 0.0f)) return false;
+      if (!(dot3(nd, n) > 0.0f)) {
+        if (ALWAYS_OUT) { tr *= s.ar; tg *= s.ag; tb *= s.ab; d_next = nd; }
+        return false;
+      }
     }
     tr *= s.ar; tg *= s.ag; tb *= s.ab;
   }
   d_next = nd;
   return true;
+}
+
+// shade_at_ball: shade_at with the point of randomInUnitSphere (b, |b|^2 = l2) already drawn from g by the
+// caller; a dielectric ignores it (and must not have had it drawn).
+RTOW_HD bool shade_at_ball(const SphereShade& s, f3 p, f3 u, Stream& g, f3 b, float l2, f3& d_next,
+                           float& tr, float& tg, float& tb) {
+  f3 n = {(p.x - s.cx) * s.inv_r, (p.y - s.cy) * s.inv_r, (p.z - s.cz) * s.inv_r};
+  const bool front = dot3(u, n) < 0.0f;  // setFaceNormal, hitrecord.nim:51-53
+  if (!front) { n.x = -n.x; n.y = -n.y; n.z = -n.z; }
+  return scatter_ball<false>(s, n, front, u, g, b, l2, d_next, tr, tg, tb);
 }
 
 RTOW_HD bool shade_at(const SphereShade& s, f3 p, f3 u, Stream& g, f3& d_next, float& tr, float& tg, float& tb) {

@@ -1,7 +1,7 @@
 // Command-line driver: main of raytracer.nim (:113-138) with its constants as defaults.
 //   rtow_raytracer [--width W] [--ratio R] [--spp N] [--depth D] [--scene random|mix|redblue]
 //                  [--half-extent E] [--out file.ppm] [--device K | --devices K0,K1,...] [--dump-scene]
-//                  [--probe S T]   getRay(camera, S, T), then hit and rayColor of that ray: one line of numbers
+//                  [--probe S T]   getRay(camera, S, T), then hit, rayColor and scatter of that ray: one line of numbers
 // --devices spreads the frame over several GPUs (an index may repeat); the image does not change.
 #include <cstdlib>
 #include <cstring>
@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     const Camera cam = scene == "random" ? bookCamera(ratio)
                        : scene == "mix"  ? initCamera(point(3, 3, 2), point(0, 0, -1), vec3(0, 1, 0), 20, ratio, 2.0, std::sqrt(27.0))
                                          : initCamera(point(0, 0, 0), point(0, 0, -1), vec3(0, 1, 0), 90, ratio, 0.0, 1.0);
-    if (probe) {  // the reference's per-ray procs through the C++ host: getRay, hit, rayColor
+    if (probe) {  // the reference's per-ray procs through the C++ host: getRay, hit, rayColor, scatter
       Device dev(device);
       dev.setWorld(world);
       dev.setCamera(cam);
@@ -65,9 +65,14 @@ int main(int argc, char** argv) {
       HitRecord rec;
       const bool h = hit(world, dev, r, 0.001, INFINITY, rec);
       const Color c = rayColor(r, dev, depth);
-      std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %.17g %.17g %.17g\n",
+      Color att = color(0, 0, 0);
+      Ray sc;
+      const bool s = h && scatter(rec.mat, dev, r, rec, att, sc);
+      std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %d %.17g %.17g %.17g "
+                  "%d %.17g %.17g %.17g %.17g %.17g %.17g\n",
                   r.orig[0], r.orig[1], r.orig[2], r.dir[0], r.dir[1], r.dir[2], (int)h, rec.index, rec.t, rec.p[0], rec.p[1],
-                  rec.p[2], rec.normal[0], rec.normal[1], rec.normal[2], (int)rec.frontFace, c[0], c[1], c[2]);
+                  rec.p[2], rec.normal[0], rec.normal[1], rec.normal[2], (int)rec.frontFace, c[0], c[1], c[2],
+                  (int)s, att[0], att[1], att[2], sc.dir[0], sc.dir[1], sc.dir[2]);
       return 0;
     }
     if (!devices.empty()) {

@@ -141,6 +141,20 @@ inline bool hit(const HittablesList& h, Device& dev, const Ray& r, double t_min,
   return true;
 }
 
+// scatter*(m, r_in, rec, attenuation, scattered)  (hitrecord.nim:127-132); draws from the stream of path
+// (pixel 0, sample 0) of `seed` instead of the reference's global generator
+inline bool scatter(const Material& m, Device& dev, const Ray& r_in, const HitRecord& rec, Color& attenuation, Ray& scattered,
+                    uint64_t seed = kRenderSeed) {
+  const uint8_t kind = (uint8_t)m.kind, front = rec.frontFace ? 1 : 0;
+  const Color a = m.kind == mkLambertian ? m.mLambertian.albedo : m.kind == mkMetal ? m.mMetal.albedo : color(1, 1, 1);
+  const double fuzz = m.kind == mkMetal ? m.mMetal.fuzz : 0.0, ir = m.kind == mkDielectric ? m.mDielectric.ir : 1.0;
+  uint8_t ok = 0;
+  scattered.orig = rec.p;
+  check(rtow_scatter_rays(dev.ctx(), 1, r_in.dir.arr.data(), rec.normal.arr.data(), &front, &kind, a.arr.data(), &fuzz, &ir, seed,
+                          attenuation.arr.data(), scattered.dir.arr.data(), &ok), "rtow_scatter_rays");
+  return ok != 0;
+}
+
 // getRay*(c, s, t)  (camera.nim:34-39) for the camera `dev` holds
 inline Ray getRay(Device& dev, double s, double t, uint64_t seed = kRenderSeed) {
   Ray r;

@@ -140,6 +140,28 @@ class Renderer:
         self._check(self._lib.rtow_get_rays(self._h, n, ptr(s), ptr(t), seed, ptr(o), ptr(d)))
         return o, d
 
+    def scatterRays(self, directions, normals, front_face, kind, albedo, fuzz, ir, seed=RENDER_SEED):
+        """scatter for a batch of (material, incoming ray, hit record) triples (rtow_scatter_rays):
+        directions, normals, albedo float64 [n, 3]; front_face, kind [n]; fuzz, ir float64 [n].  Returns
+        (attenuation [n, 3], scattered direction [n, 3], scattered bool [n]); triple i draws from the stream
+        of path (pixel i, sample 0)."""
+        d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        nn = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+        al = np.ascontiguousarray(albedo, dtype=np.float64).reshape(-1, 3)
+        ff = np.ascontiguousarray(front_face, dtype=np.uint8).reshape(-1)
+        kk = np.ascontiguousarray(kind, dtype=np.uint8).reshape(-1)
+        fz = np.ascontiguousarray(fuzz, dtype=np.float64).reshape(-1)
+        ii = np.ascontiguousarray(ir, dtype=np.float64).reshape(-1)
+        n = d.shape[0]
+        if not (nn.shape[0] == al.shape[0] == ff.shape[0] == kk.shape[0] == fz.shape[0] == ii.shape[0] == n):
+            raise ValueError("scatterRays: the arrays differ in length")
+        att, out = np.zeros((n, 3), np.float64), np.zeros((n, 3), np.float64)
+        ok = np.zeros(n, np.uint8)
+        ptr = lambda a: a.ctypes.data if a.size else None  # noqa: E731
+        self._check(self._lib.rtow_scatter_rays(self._h, n, ptr(d), ptr(nn), ptr(ff), ptr(kk), ptr(al), ptr(fz), ptr(ii),
+                                                seed, ptr(att), ptr(out), ptr(ok)))
+        return att, out, ok.astype(bool)
+
     def renderNoAlloc(self, width, height, samplesPerPixel, maxDepth, rgb_dev, seed=RENDER_SEED, rows_dev=None,
                       n_rows=None):
         """Enqueue a render that allocates nothing (rtow_render_noalloc): rgb_dev and rows_dev are
@@ -252,6 +274,20 @@ def hit(world, r, t_min, t_max, rec):
     rec.mat = s.mat
     rec.index = int(hid[0])
     return True
+
+
+def scatter(m, r_in, rec, seed=RENDER_SEED, index=0):
+    """scatter*(m: Material, r_in: Ray, rec: HitRecord, attenuation: var Color, scattered: var Ray): bool
+    (hitrecord.nim:127-132).  Python has no var parameters: returns (result, attenuation, scattered).  Draws
+    from the stream of path (pixel `index`, sample 0) of `seed` instead of the global generator."""
+    dev = _shared_renderer()
+    n = index + 1
+    kind, albedo, fuzz, ir = m.flat()
+    att, out, ok = dev.scatterRays(np.tile(np.asarray(list(r_in.dir), np.float64), (n, 1)),
+                                   np.tile(np.asarray(list(rec.normal), np.float64), (n, 1)),
+                                   [1 if rec.frontFace else 0] * n, [kind] * n, np.tile(np.asarray(albedo, np.float64), (n, 1)),
+                                   [fuzz] * n, [ir] * n, seed=seed)
+    return bool(ok[index]), Color(*att[index]), Ray(Point(*rec.p), Vec3(*out[index]))
 
 
 def getRay(c, s, t, seed=RENDER_SEED, index=0):

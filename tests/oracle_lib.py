@@ -96,6 +96,7 @@ def lib():
     L.orc_ref64_ray_color.restype = None
     L.orc_mirror32_trace_ray.argtypes = [C.POINTER(Sphere), C.c_int, dp, dp, C.c_double, C.c_double, C.c_int, C.c_uint64,
                                          C.c_uint32, dp, dp]
+    L.orc_mirror32_scatter.argtypes = [C.POINTER(Sphere), dp, dp, C.c_int, C.c_uint64, C.c_uint32, dp, dp]
     L.orc_ref64_set_variant.argtypes = [C.c_int]
     L.orc_ref64_set_variant.restype = None
     _lib = L

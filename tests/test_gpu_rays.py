@@ -1,5 +1,6 @@
 """The reference's per-ray procs on the GPU - hit (hittables.nim:79, hitrecord.nim:55), rayColor
-(raytracer.nim:5), getRay (camera.nim:34) - through rtow_trace_rays / rtow_get_rays, against the oracle's
+(raytracer.nim:5), getRay (camera.nim:34), scatter (hitrecord.nim:127) - through rtow_trace_rays /
+rtow_get_rays / rtow_scatter_rays, against the oracle's
 single-ray probes.  The first world.hit of a ray is evaluated in binary64 with the reference's operations, so
 hit index and t must EQUAL the FP64 restatement's (oracle/ref64.c); colours must equal the renderer's CPU
 mirror bit for bit, and the FP64 restatement's exactly at depth 1 and closely at depth 50."""
@@ -149,7 +150,7 @@ def test_reference_signatures(oracle, book_scene):
 
 
 def test_cpp_host_per_ray_procs(oracle, book_scene):
-    """getRay, hit and rayColor of the compiled host (raytracinginoneweekend_amd/host) through its CLI."""
+    """getRay, hit, rayColor and scatter of the compiled host (raytracinginoneweekend_amd/host) through its CLI."""
     import os
     import subprocess
     from conftest import ROOT
@@ -177,6 +178,11 @@ def test_cpp_host_per_ray_procs(oracle, book_scene):
         c = (C.c_double * 3)()
         L.orc_mirror32_trace_ray(arr, n, _dp(o), _dp(d), 0.001, math.inf, 50, 0xE7, 0, c, C.byref(tt))
         assert [float(x) for x in v[16:19]] == list(c)
+        if want >= 0:   # scatter(rec.mat, r, rec) on that hit, stream of path (pixel 0, sample 0)
+            a32, o32 = (C.c_double * 3)(), (C.c_double * 3)()
+            nrm = np.array([float(x) for x in v[12:15]])
+            ok32 = L.orc_mirror32_scatter(C.byref(arr[want]), _dp(d), _dp(nrm), int(v[15]), 0xE7, 0, a32, o32)
+            assert int(v[19]) == ok32 and [float(x) for x in v[20:23]] == list(a32) and [float(x) for x in v[23:26]] == list(o32)
 
 
 def test_ray_entry_point_errors(gpu_renderer):
@@ -197,3 +203,81 @@ def test_ray_entry_point_errors(gpu_renderer):
         with pytest.raises(_lib.RtowError) as e:
             fresh.getRays([0.5], [0.5])
         assert e.value.status == -3
+
+
+def _scatter_cases(rng, n):
+    """Random (material, incoming ray, hit record) triples: unit normals turned against the rays, directions of
+    any length, all three material kinds, grazing and head-on incidence."""
+    nrm = rng.normal(0.0, 1.0, (n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    d = rng.normal(0.0, 1.0, (n, 3))
+    flip = np.einsum("ij,ij->i", d, nrm) > 0
+    d[flip] = -d[flip]                                   # rec.normal always faces the ray (hitrecord.nim:51-53)
+    d *= np.exp(rng.uniform(-3.0, 3.0, (n, 1)))
+    kind = rng.integers(0, 3, n).astype(np.uint8)
+    albedo = rng.uniform(0.0, 1.0, (n, 3))
+    fuzz = np.where(rng.uniform(size=n) < 0.3, 0.0, rng.uniform(0.0, 1.0, n))
+    ir = np.where(rng.uniform(size=n) < 0.5, 1.5, rng.uniform(1.05, 2.4, n))
+    front = rng.integers(0, 2, n).astype(np.uint8)
+    return d, nrm, front, kind, albedo, fuzz, ir
+
+
+def test_scatter_against_mirror_and_fp64_restatement(gpu_renderer, oracle):
+    """scatter (hitrecord.nim:127-132) through rtow_scatter_rays: attenuation, scattered direction and result
+    equal the renderer's CPU mirror bit for bit, and the FP64 restatement of the reference closely (same draws:
+    a decision that differs needs a value within rounding of its threshold)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    n = 4000
+    d, nrm, front, kind, albedo, fuzz, ir = _scatter_cases(rng, n)
+    seed = 0xE7
+    att, out, ok = gpu_renderer.scatterRays(d, nrm, front, kind, albedo, fuzz, ir, seed=seed)
+    assert att.shape == out.shape == (n, 3) and ok.shape == (n,)
+    key = (C.c_uint32 * 2)()
+    zero = (C.c_double * 3)(0.0, 0.0, 0.0)
+    differing_decisions = 0
+    absorbed = 0
+    for i in range(n):
+        arr, _ = oracle.spheres_from_arrays([(0, 0, 0)], [1.0], [kind[i]], [albedo[i]], [fuzz[i]], [ir[i]])
+        a32, o32 = (C.c_double * 3)(), (C.c_double * 3)()
+        ok32 = L.orc_mirror32_scatter(arr, _dp(d[i]), _dp(nrm[i]), int(front[i]), seed, i, a32, o32)
+        assert bool(ok32) == bool(ok[i]), i
+        assert list(a32) == list(att[i]) and list(o32) == list(out[i]), (i, kind[i], list(o32), list(out[i]))
+        absorbed += not ok32
+        L.orc_path_key(seed, i, 0, key)
+        k = C.c_uint32(0)
+        a64, oo, o64 = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_double * 3)()
+        ok64 = L.orc_ref64_scatter(arr, zero, _dp(d[i]), zero, _dp(nrm[i]), int(front[i]), key, C.byref(k), a64, oo, o64)
+        want = np.array(list(o64))
+        if bool(ok64) != bool(ok[i]) or not np.allclose(out[i], want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max())):
+            differing_decisions += 1                      # reflect / refract, or a near-zero test, decided the other way
+            continue
+        if kind[i] == 2:
+            assert list(a64) == [1.0, 1.0, 1.0] == list(att[i])
+        else:
+            assert np.allclose(att[i], list(a64), rtol=1e-6, atol=0)
+    assert absorbed > 20                                   # fuzzed metal reflections below the surface occur
+    assert differing_decisions <= n // 500
+    assert gpu_renderer.scatterRays(d[:0], nrm[:0], front[:0], kind[:0], albedo[:0], fuzz[:0], ir[:0])[2].shape == (0,)
+
+
+def test_scatter_wrapper_and_errors(gpu_renderer, oracle):
+    """The host proc with the reference's parameter list, chained after hit: scatter(rec.mat, r, rec)."""
+    R = _R()
+    from raytracinginoneweekend_amd import _lib, basetypes as B, hitrecord as HR
+    world = R.randomScene()
+    r = B.initRay(B.point(13, 2, 3), B.vec3(-13, -1.5, -3))
+    rec = HR.HitRecord()
+    assert R.hit(world, r, 0.001, math.inf, rec)
+    ok, att, sc = R.scatter(rec.mat, r, rec, index=3)
+    arr, _ = oracle.spheres_from_arrays([(0, 0, 0)], [1.0], *[[x] for x in rec.mat.flat()])
+    a32, o32 = (C.c_double * 3)(), (C.c_double * 3)()
+    d = np.asarray(list(r.dir), np.float64)
+    nn = np.asarray(list(rec.normal), np.float64)
+    ok32 = oracle.lib().orc_mirror32_scatter(arr, _dp(d), _dp(nn), int(rec.frontFace), R.RENDER_SEED, 3, a32, o32)
+    assert ok == bool(ok32) and list(att) == list(a32) and list(sc.dir) == list(o32) and list(sc.orig) == list(rec.p)
+    with pytest.raises(_lib.RtowError) as e:
+        gpu_renderer.scatterRays([[0, 0, -1]], [[0, 0, 1]], [1], [7], [[1, 1, 1]], [0.0], [1.5])
+    assert e.value.status == -1 and "kind" in str(e.value)
+    with pytest.raises(_lib.RtowError):
+        gpu_renderer.scatterRays([[0, 0, -1]], [[0, 0, 1]], [1], [2], [[1, 1, 1]], [0.0], [0.0])

@@ -277,3 +277,39 @@ def test_sphere_screen_never_drops_a_true_hit(oracle, book_scene):
         for x, y in zip(plain[:3], audited[:3]):
             assert (x == y).all(), name
         assert plain[3] == audited[3], name
+
+
+def test_mirror_scatter_tracks_the_fp64_scatter(oracle):
+    """The binary32 restatement of scatter (hitrecord.nim:82-132) against the binary64 one on the same draws:
+    same decisions except within rounding of a threshold, directions within binary32 rounding."""
+    import ctypes as C
+    import numpy as np
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    n = 1500
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    key = (C.c_uint32 * 2)()
+    zero = (C.c_double * 3)(0.0, 0.0, 0.0)
+    other = 0
+    kinds = [0, 0, 0]
+    for i in range(n):
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        d = rng.normal(size=3)
+        if d @ nrm > 0:
+            d = -d
+        d *= np.exp(rng.uniform(-2, 2))
+        kind = int(rng.integers(0, 3))
+        arr, _ = oracle.spheres_from_arrays([(0, 0, 0)], [1.0], [kind], [rng.uniform(0, 1, 3)], [rng.uniform(0, 1)], [rng.uniform(1.1, 2.4)])
+        front = int(rng.integers(0, 2))
+        a32, o32 = (C.c_double * 3)(), (C.c_double * 3)()
+        ok32 = L.orc_mirror32_scatter(arr, dp(d), dp(nrm), front, 0xE7, i, a32, o32)
+        L.orc_path_key(0xE7, i, 0, key)
+        k = C.c_uint32(0)
+        a64, oo, o64 = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_double * 3)()
+        ok64 = L.orc_ref64_scatter(arr, zero, dp(d), zero, dp(nrm), front, key, C.byref(k), a64, oo, o64)
+        if ok32 != ok64 or not np.allclose(list(o32), list(o64), rtol=0, atol=2e-5 * max(1.0, np.abs(list(o64)).max())):
+            other += 1
+            continue
+        kinds[kind] += 1
+        assert np.allclose(list(a32), list(a64), rtol=1e-6, atol=0)
+    assert other <= 3 and min(kinds) > 300
