@@ -554,6 +554,33 @@ def test_large_tables_and_material_variants(oracle):
             assert r.stats()["ray_segments"] == ref[3]
 
 
+def test_table_sizes_around_the_lds_thresholds(oracle):
+    """The kernel has three instances by table size: all tables in LDS (up to 512 padded entries), -k alone
+    in LDS (up to 4096), everything through scalar loads (beyond).  Lists just below, at and just above both
+    thresholds - a ground sphere first, so the binary64 list is non-empty - bit-exact against the mirror."""
+    R = _R()
+    W, H, spp = 56, 40, 2
+    rng = np.random.default_rng(77)
+    with R.Renderer(0) as r:
+        r.setCamera(R.bookCamera(W / H))
+        for n in (503, 504, 505, 511, 512, 513, 520, 4087, 4088, 4089, 4096, 4097, 4105):
+            center = np.column_stack([rng.uniform(-11, 11, n), np.full(n, 0.2), rng.uniform(-11, 11, n)])
+            radius = np.full(n, 0.2)
+            center[0], radius[0] = (0.0, -1000.0, 0.0), 1000.0
+            kind = rng.integers(0, 3, n)
+            albedo = rng.uniform(0.0, 1.0, (n, 3))
+            fuzz = rng.uniform(0.0, 0.5, n)
+            ir = np.full(n, 1.5)
+            r.setWorld({"center_x": center[:, 0], "center_y": center[:, 1], "center_z": center[:, 2], "radius": radius,
+                        "kind": kind, "albedo": albedo, "fuzz": fuzz, "ir": ir})
+            assert r.n_spheres == n
+            arr, k = oracle.spheres_from_arrays(center, radius, kind, albedo, fuzz, ir)
+            got = r.renderRows(W, H, spp, 50, want_accum=True, want_hit_id=True)
+            ref = oracle.render_mirror32(arr, k, oracle.book_camera(W / H), W, H, spp, 50, threads=16)
+            _check_bit_exact(got, ref)
+            assert r.stats()["ray_segments"] == ref[3], n
+
+
 def test_smallest_frame_and_depth_one(oracle, book_scene):
     """2x2 frame (the smallest the reference's (W-1)/(H-1) divisors allow), one sample, and a
     deep-sample single pixel row: edge sizes of the work distribution (one lane busy, one chunk)."""
