@@ -24,8 +24,12 @@
  *   - deviations from the reference in the binary32 segments, both to keep rounding noise out of the
  *     image: a ray scattered on sphere j can meet j again only at its far root (the reference would
  *     accept any root >= t_min, including a near root that rounding has pushed above it), and one
- *     sample's channel radiance is clamped to [0, 3.5] before it is summed in 30-bit fixed point (never
+ *     sample's channel radiance is clamped to [0, 3.5] before it is summed in fixed point (never
  *     reached while albedos are <= 1, which rtow_set_scene enforces);
+ *   - a pixel's channel sums are 64-bit integers in units of 2^-40.  A binary32 sample is cut to 30
+ *     fractional bits before it is added, the binary64 sky colour of a camera ray to 40; writeColor
+ *     (raytracer.nim:22-28) then runs in binary64 on the sum.  At one sample per pixel the 8-bit value
+ *     is therefore the reference's unless a channel lies within 2^-40 above a quantisation boundary;
  *   - randomness: draw k of path (pixel, sample) is a pure function of (seed, pixel, sample, k),
  *     pixel = y*w + x with y = 0 the top image row.  It replaces the reference's single global
  *     std/random stream (raytracer.nim:41-42,135; basetypes.nim:112,132; hitrecord.nim:119),
@@ -129,9 +133,10 @@ int rtow_set_camera_f64(rtow_ctx* ctx, const rtow_camera_f64* cam);
  * row, the first one the reference writes.  rows == NULL means rows 0..h-1 (then n_rows must be
  * h).  Outputs are n_rows x w in rows[] order, host pointers, any may be NULL:
  *   rgb_out      3 bytes per pixel: the three integers writeColor prints (raytracer.nim:28)
- *   accum_out    3 uint64 per pixel: per-channel radiance sums, fixed point, 30 fractional bits
+ *   accum_out    3 uint64 per pixel: per-channel radiance sums, fixed point, 40 fractional bits
  *   hit_id_out   list index hit by the primary ray of sample 0, -1 for the sky (debug plane)
- * Blocks until the image is in host memory.  w,h >= 2; spp,max_depth >= 1. */
+ * Blocks until the image is in host memory.  w,h >= 2; max_depth >= 1; 1 <= spp <= 4 194 304 (what the
+ * 64-bit sums hold; the limit applies to all the samples of a pixel, passes of rtow_render_pass included). */
 int rtow_render(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uint64_t seed,
                 const int32_t* rows, int n_rows, uint8_t* rgb_out, uint64_t* accum_out,
                 int32_t* hit_id_out);

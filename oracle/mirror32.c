@@ -38,9 +38,9 @@
  *     (normal, scatter, throughput as for every later segment, with the binary32 unit direction
  *     of the rounded primary direction);
  *   - a uniform draw is (u32 >> 8) * 2^-24, so rand(-1.0..1.0) = 2*xi - 1 is exact;
- *   - per-sample radiance is accumulated per channel as a 64-bit integer with 30 fractional
- *     bits (order independent), and the writeColor step (raytracer.nim:22-28) runs in binary64
- *     on that sum.
+ *   - per-sample radiance is accumulated per channel as a 64-bit integer with 40 fractional
+ *     bits (order independent) - a binary32 sample is cut to 30 first, a binary64 sky sample keeps
+ *     all 40 - and the writeColor step (raytracer.nim:22-28) runs in binary64 on that sum.
  */
 #include "rtow_oracle.h"
 #include <math.h>
@@ -73,7 +73,9 @@ typedef struct {
 
 #define BIG_RADIUS 100.0f
 #define FILTER_MARGIN (1.0f / 262144.0f) /* 2^-18 */
-#define FIX_ONE 1073741824.0f /* 2^30 */
+#define FIX_ONE 1073741824.0f /* 2^30: scale of a binary32 sample */
+#define SUM_SHIFT 10
+#define SUM_ONE 1099511627776.0 /* 2^40: scale of the sums */
 #define RADIANCE_CLAMP 3.5f
 
 static void prep_scene(const orc_sphere* in, int n, sph32* out, float* cmax) {
@@ -269,10 +271,10 @@ static int primary_hit(const sph32* w, int n, float cmax, const double o64[3], c
   return id;
 }
 
-/* one channel of a binary64 sample -> fixed point, 30 fractional bits, truncated */
+/* one channel of a binary64 sample -> sum units: fixed point, 40 fractional bits, truncated */
 static inline uint64_t to_fix64(double c) {
   c = c < 0.0 ? 0.0 : (c > (double)RADIANCE_CLAMP ? (double)RADIANCE_CLAMP : c);
-  return (uint64_t)(uint32_t)(c * 1073741824.0);
+  return (uint64_t)(c * SUM_ONE);
 }
 
 typedef struct {
@@ -282,9 +284,10 @@ typedef struct {
   uint8_t* rgb; uint64_t* accum; int32_t* hit_id; uint64_t segments;
 } job32;
 
+/* one channel of a binary32 sample: cut to 30 fractional bits (it then fits 32 bits), widened to sum units */
 static inline uint64_t to_fix(float c) {
   c = fminf(fmaxf(c, 0.0f), RADIANCE_CLAMP);
-  return (uint64_t)(uint32_t)(c * FIX_ONE);
+  return (uint64_t)(uint32_t)(c * FIX_ONE) << SUM_SHIFT;
 }
 
 /* scatter (hitrecord.nim:82-132) in binary32: n is the face-set unit normal, front the frontFace flag, u the
@@ -436,7 +439,7 @@ static void trace_path(const job32* jb, int i, int j, uint32_t pixel, uint32_t s
 }
 
 static int quantise_fix(uint64_t sum, int spp) {
-  const double mean = (double)sum / ((double)spp * 1073741824.0);
+  const double mean = (double)sum / ((double)spp * SUM_ONE);
   double v = sqrt(mean);
   v = v < 0.0 ? 0.0 : (v > 0.999 ? 0.999 : v);
   return (int)(256.0 * v);

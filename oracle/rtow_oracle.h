@@ -98,7 +98,7 @@ int orc_ref64_render(const orc_sphere* spheres, int n_spheres, const orc_camera*
 void orc_ref64_set_variant(int v);
 
 /* FP32 mirror of the GPU arithmetic.  accum_fix: 3 x uint64 per pixel, fixed-point sums with
- * 30 fractional bits (what the kernels accumulate). */
+ * 40 fractional bits (what the kernels accumulate). */
 int orc_mirror32_render(const orc_sphere* spheres, int n_spheres, const orc_camera* cam,
                         int W, int H, int spp, int max_depth, uint64_t seed,
                         const int32_t* rows, int n_rows, int n_threads,

@@ -518,8 +518,9 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   if (rows)
     for (int r = 0; r < n_rows; ++r)
       if (rows[r] < 0 || rows[r] >= h) return fail(RTOW_ERR_INVALID, "render: rows[%d] = %d of %d", r, rows[r], h);
-  if (first_sample < 0 || (int64_t)first_sample + spp > 0x7fffffff)
-    return fail(RTOW_ERR_INVALID, "render: samples %d .. %lld", first_sample, (long long)first_sample + spp - 1);
+  if (first_sample < 0 || (int64_t)first_sample + spp > rtow::kMaxSamplesPerPixel)
+    return fail(RTOW_ERR_INVALID, "render: samples %d .. %lld (a pixel's 64-bit sums hold at most %d samples)", first_sample,
+                (long long)first_sample + spp - 1, rtow::kMaxSamplesPerPixel);
   if (first_sample > 0) {
     const bool same_rows = rows ? (c->last_row_list_valid && c->last_row_list.size() == (size_t)n_rows &&
                                    std::equal(c->last_row_list.begin(), c->last_row_list.end(), rows))

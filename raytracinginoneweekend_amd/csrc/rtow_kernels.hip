@@ -536,9 +536,9 @@ static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum
   lds_order();
 }
 
-// Must be called by all 64 lanes together; lanes with `want` set add (acc_r, acc_g, acc_b) to pixel accpix.
+// Must be called by all 64 lanes together; lanes with `want` set add (acc_r, acc_g, acc_b), in sum units, to pixel accpix.
 static __device__ __forceinline__ void flush_sums(unsigned long long* accum, SumCache& c, bool want, uint32_t accpix,
-                                                  uint32_t acc_r, uint32_t acc_g, uint32_t acc_b, uint32_t lane) {
+                                                  uint64_t acc_r, uint64_t acc_g, uint64_t acc_b, uint32_t lane) {
   uint64_t todo = __ballot(want);
   while (todo != 0) {
     const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       Stream g2 = {pool[12 * 64 + lane], pool[13 * 64 + lane]};
       lds_order();   // every lane has read its ray before the pool entries below overwrite the rays
       const uint32_t pix2 = p_base - dp;
-      uint32_t fr = 0, fg = 0, fb = 0;
+      uint64_t fr = 0, fg = 0, fb = 0;
       bool sky = false, cont = false;
       f3 p = {0, 0, 0}, dn = {0, 0, 1};
       float ptr_ = 1.0f, ptg_ = 1.0f, ptb_ = 1.0f;
@@ -968,7 +968,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           alive = false;
         }
       }
-      flush_sums(P.accum, sums, (fr | fg | fb) != 0u, pix, fr, fg, fb, lane);
+      flush_sums(P.accum, sums, (fr | fg | fb) != 0u, pix, widen_fix(fr), widen_fix(fg), widen_fix(fb), lane);
     }
     RTOW_COUNT(3, 1);
 #ifdef RTOW_PROFILE_COUNTERS

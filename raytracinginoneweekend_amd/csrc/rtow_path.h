@@ -21,9 +21,15 @@
 namespace rtow {
 
 constexpr float kBigRadius = 100.0f;        // |r| >= this: intersect in binary64
-constexpr float kFixOne = 1073741824.0f;    // 2^30: fixed-point scale of radiance sums
-constexpr double kFixOneD = 1073741824.0;
-constexpr float kRadianceClamp = 3.5f;      // keeps one sample's channel inside 32 bits
+// Radiance sums are 64-bit integers in units of 2^-40.  A sample computed in binary32 is cut to 30
+// fractional bits first (it then fits 32 bits) and widened by a shift; a sample computed in binary64 - the
+// sky colour of a camera ray that hits nothing - keeps all 40, so that the 8-bit value of a one-sample
+// pixel is the reference's except when its channel lies within 2^-40 above a quantisation boundary.
+constexpr float kFixOne = 1073741824.0f;    // 2^30: scale of a binary32 sample
+constexpr int kSumShift = 10;               // 2^30 -> 2^40
+constexpr double kSumOneD = 1099511627776.0;   // 2^40: scale of the sums
+constexpr int kMaxSamplesPerPixel = 1 << 22;   // 2^22 * 3.5 * 2^40 < 2^64
+constexpr float kRadianceClamp = 3.5f;      // keeps one binary32 sample's channel inside 32 bits
 constexpr float kTMin = 0.001f;             // raytracer.nim:11, in units of |dir|
 constexpr uint32_t kGolden = 0x9E3779B9u;
 
@@ -354,22 +360,23 @@ RTOW_HD bool shade_hit(const SphereShade& s, f3& o, f3 u, float t, Stream& g, f3
   return shade_at(s, p, u, g, d_next, tr, tg, tb);
 }
 
-// one sample's channel radiance -> fixed point (30 fractional bits)
+// one binary32 sample's channel radiance -> fixed point with 30 fractional bits; widen_fix() puts it in sum units
 RTOW_HD uint32_t to_fix(float c) {
   c = fminf(fmaxf(c, 0.0f), kRadianceClamp);
   return (uint32_t)(c * kFixOne);
 }
+RTOW_HD uint64_t widen_fix(uint32_t v) { return (uint64_t)v << kSumShift; }
 
-// the same for a sample evaluated in binary64 (the sky colour of a primary miss)
-RTOW_HD uint32_t to_fix64(double c) {
+// a sample evaluated in binary64 (the sky colour of a primary miss) -> sum units (40 fractional bits, truncated)
+RTOW_HD uint64_t to_fix64(double c) {
   c = c < 0.0 ? 0.0 : (c > (double)kRadianceClamp ? (double)kRadianceClamp : c);
-  return (uint32_t)(c * kFixOneD);
+  return (uint64_t)(c * kSumOneD);
 }
 
 // writeColor (raytracer.nim:22-28) on a fixed-point channel sum: mean, sqrt gamma,
 // clamp(0, 0.999), 256x, truncate.  Runs in binary64.
 RTOW_HD int quantise_fix(uint64_t sum, int spp) {
-  const double mean = (double)sum / ((double)spp * kFixOneD);
+  const double mean = (double)sum / ((double)spp * kSumOneD);
   double v = sqrt(mean);
   v = v < 0.0 ? 0.0 : (v > 0.999 ? 0.999 : v);
   return (int)(256.0 * v);

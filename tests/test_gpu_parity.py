@@ -195,7 +195,7 @@ def test_converged_image_against_fp64_reference(gpu_renderer, oracle, book_scene
     assert np.mean(np.abs(rgb.astype(np.int32) - f_rgb.astype(np.int32))) <= 0.25
     assert np.mean(hid != f_hid) < 1e-3
     assert abs(gpu_renderer.stats()["ray_segments"] - f_seg) / f_seg < 2e-3
-    lin = acc.astype(np.float64) / (spp * 2.0 ** 30)
+    lin = acc.astype(np.float64) / (spp * 2.0 ** 40)
     assert abs(lin.mean() - (f_acc / spp).mean()) < 2e-4
     # the committed FP64 fixture (100x67, spp 64)
     g = np.load(os.path.join(GOLDEN, "ref64_100x67_spp64_d50.npz"))
@@ -251,7 +251,7 @@ def test_ten_thousand_spheres(oracle):
         st = r.stats()
         assert st["paths"] == W * H and st["paths"] <= st["ray_segments"] <= 50 * st["paths"] and st["n_spheres"] == n
         assert (hid[0] == -1).all() and hid.max() <= n - 1 and (hid[-1] >= 0).all()
-        assert (rgb[0, :, 2] == 255).all() and acc.max() <= 2 ** 30
+        assert (rgb[0, :, 2] == 255).all() and acc.max() <= 2 ** 40
         rows = [0, 1079, 1080, 2159]
         m = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, 1, 50, rows=rows, threads=16)
         assert (rgb[rows] == m[0]).all() and (acc[rows] == m[1]).all() and (hid[rows] == m[2]).all()
@@ -386,10 +386,18 @@ def test_error_behaviour(gpu_renderer):
     from raytracinginoneweekend_amd import _lib
     R = _R()
     gpu_renderer.setCamera(R.bookCamera(1.5))
-    for args in ((1, 10, 1, 1), (10, 1, 1, 1), (10, 10, 0, 1), (10, 10, 1, 0)):
+    for args in ((1, 10, 1, 1), (10, 1, 1, 1), (10, 10, 0, 1), (10, 10, 1, 0), (10, 10, 2 ** 22 + 1, 1)):
         with pytest.raises(_lib.RtowError) as e:
             gpu_renderer.renderRows(*args)
         assert e.value.status == -1
+    # the 64-bit sums hold 2^22 samples of a pixel (units of 2^-40, at most 3.5 per sample and channel)
+    from raytracinginoneweekend_amd.hittables import initHittables
+    with R.Renderer(0) as sky:
+        sky.setWorld(initHittables(0))
+        sky.setCamera(R.bookCamera(1.0))
+        rgb, acc, _ = sky.renderRows(2, 2, 2 ** 22, 1, want_accum=True)
+        assert (acc[..., 2] == 2 ** 62).all() and (rgb[..., 2] == 255).all()     # the sky's blue channel is 1.0 in every sample
+        assert (acc[..., :2] < 2 ** 62).all() and (acc[..., :2] > 2 ** 61).all()
     with pytest.raises(_lib.RtowError):
         gpu_renderer.renderRows(10, 10, 1, 1, rows=[10])
     with pytest.raises(_lib.RtowError):
@@ -428,8 +436,8 @@ def test_full_size_properties(gpu_renderer, oracle, book_scene):
     assert (band[1] == acc[rows]).all()
     m = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, spp, depth, rows=rows, threads=16)
     assert (band[0] == m[0]).all() and (band[1] == m[1]).all()
-    # sums are bounded by spp * 2^30 per channel for this scene (all albedos <= 1)
-    assert acc.max() <= spp * 2 ** 30
+    # sums are bounded by spp * 2^40 per channel for this scene (all albedos <= 1)
+    assert acc.max() <= spp * 2 ** 40
 
 
 @pytest.mark.parametrize("variant", [{}, {"lambert_below": 0.0, "metal_below": 0.5}])

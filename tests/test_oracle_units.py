@@ -219,7 +219,7 @@ def test_mirror32_tracks_ref64(oracle, book_scene):
     assert np.mean(h64 != h32) < 1e-3  # primary hits differ only on silhouette pixels
     assert abs(s64 - s32) / s64 < 2e-3
     lin64 = a64 / spp
-    lin32 = a32.astype(np.float64) / (spp * 2.0 ** 30)
+    lin32 = a32.astype(np.float64) / (spp * 2.0 ** 40)
     assert abs(lin64.mean() - lin32.mean()) < 2e-4
 
 
