@@ -208,6 +208,7 @@ def main():
     serial_ms = sorted(serial_wall)[1]                      # medians of three: one slow launch (clock
     trace_ms = [sorted(st["trace_ms"] for st in serial)[1]]  # transients between phases) does not decide
     total_ms = [sorted(st["total_ms"] for st in serial)[1]]
+    clock_mhz = sorted(st.get("shader_clock_mhz", 0.0) for st in serial)[1]   # what the chip sustained under the kernel
 
     # the frame assembled from all ranks' tiles against the same frame rendered whole on rank 0
     image_verified = None
@@ -274,6 +275,11 @@ def main():
                 # the ~1.2 survivors per ray, so the share of the VALU peak it really issues is lower:
                 "frac_executed_screen_only": serial[-1]["ray_segments"] * FLOP_PER_TEST_EXECUTED * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS,
                 "kernel_ms": avg_trace_s * 1e3,
+                # the peak above is 256 CUs x 256 FLOP/clk at the 2.4 GHz boost clock; under this kernel the chip runs
+                # slower, and differently from box to box.  Clock read by the kernel itself (shader-clock ticks per
+                # tick of the constant 100 MHz counter over the life of its first wave):
+                "shader_clock_mhz": clock_mhz,
+                "frac_at_measured_clock": (achieved / (PEAK_FP32_VALU_TFLOPS * clock_mhz / 2400.0)) if clock_mhz > 0 else None,
                 "traffic": hbm_traffic(args.workload, spp, world),
                 "traffic_source": "constant from the committed rocprofv3 PMC passes (profiles/*_traffic.json), not measured in this run",
                 "framebuffer_GBps": (n_rows * width * 3) / (sum(total_ms) / len(total_ms) * 1e-3) / 1e9,

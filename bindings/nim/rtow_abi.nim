@@ -11,6 +11,7 @@ type
     raySegments*, paths*: uint64
     traceMs*, totalMs*: cfloat
     nSpheres*, nBig*: int32
+    shaderClockMhz*, reserved: cfloat
 
 proc rtow_last_error*(): cstring {.importc, dynlib: rtowLib.}
 proc rtow_create*(device: cint, ctx: ptr RtowCtx): cint {.importc, dynlib: rtowLib.}

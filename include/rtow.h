@@ -87,6 +87,9 @@ typedef struct {
   float total_ms;         /* device time of clear + trace + resolve (HIP events) */
   int32_t n_spheres;
   int32_t n_big;          /* spheres routed through the binary64 test */
+  float shader_clock_mhz; /* clock the GPU ran at during that kernel: shader-clock ticks per tick of the
+                             constant 100 MHz counter, read by the kernel's first wave as it starts and retires */
+  float reserved_;
 } rtow_stats;
 
 /* Message of the last failing call on this thread ("" if none). */

@@ -38,7 +38,8 @@ class CameraStruct64(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("ray_segments", C.c_uint64), ("paths", C.c_uint64), ("trace_ms", C.c_float),
-                ("total_ms", C.c_float), ("n_spheres", C.c_int32), ("n_big", C.c_int32)]
+                ("total_ms", C.c_float), ("n_spheres", C.c_int32), ("n_big", C.c_int32),
+                ("shader_clock_mhz", C.c_float), ("reserved_", C.c_float)]
 
 
 # every symbol include/rtow.h declares

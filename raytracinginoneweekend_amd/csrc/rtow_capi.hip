@@ -59,6 +59,7 @@ struct DevBuf {
 // hipMalloc.  Every GPU the library runs on holds its own copy (25 MB) until the process ends, and
 // all contexts on one GPU share it.  Layout: 256 bytes of counters (segment count, next path), then
 // three 64-bit radiance sums per pixel.
+constexpr size_t kCounterBytes = 48;   // per frame: segment count, next path, four clock stamps (8 bytes each)
 constexpr uint32_t kNoAllocMaxPixels = 1u << 20;   // 1 048 576: a 1200 x 800 frame fits
 constexpr size_t kScratchHeader = 256;
 constexpr size_t kScratchBytes = kScratchHeader + sizeof(unsigned long long) * 3 * (size_t)kNoAllocMaxPixels;
@@ -161,9 +162,9 @@ struct rtow_ctx {
   DevBuf gather;                              // rtow_render_multi over RCCL: the other GPUs' rows land here (context 0)
   uint8_t* gather_host = nullptr;             // pinned copy of it
   size_t gather_host_cap = 0;
-  DevBuf rows, accum, hit_id, rgb, counters;  // counters: [0..7] segment count (u64), [8..15] path counter (u64)
+  DevBuf rows, accum, hit_id, rgb, counters;  // counters: segment count (u64), path counter (u64), four clock stamps (u64)
   unsigned char* scratch_dev = nullptr;       // this GPU's copy of the no-allocation work memory
-  uint64_t* host_counters = nullptr;          // pinned, 16 bytes
+  uint64_t* host_counters = nullptr;          // pinned, kCounterBytes
   char* staging[2] = {nullptr, nullptr};      // pinned, kStagingBytes each: large device-to-host copies go through them
   hipEvent_t staging_ev[2] = {nullptr, nullptr};
 
@@ -210,7 +211,7 @@ extern "C" {
 
 const char* rtow_last_error(void) { return g_err.c_str(); }
 
-int rtow_version(void) { return 100; }
+int rtow_version(void) { return 101; }
 
 int rtow_device_count(int* count) {
   if (!count) return fail(RTOW_ERR_INVALID, "rtow_device_count: count is NULL");
@@ -232,8 +233,8 @@ int rtow_create(int device, rtow_ctx** out) {
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->host_counters, 16, hipHostMallocDefault);
-  if (e == hipSuccess) e = c->counters.reserve(16);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->host_counters, kCounterBytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = c->counters.reserve(kCounterBytes);
   if (e == hipSuccess && device < kMaxDevices) {
     unsigned char* p = g_scratch_ptr[device].load(std::memory_order_acquire);
     if (!p) {
@@ -441,7 +442,7 @@ int rtow_set_camera(rtow_ctx* c, const rtow_camera* cam) {
 struct FrameTargets {
   const int32_t* rows_dev = nullptr;      // device copy of rows[], or nullptr for rows 0..n_rows-1
   unsigned long long* accum = nullptr;    // n_rows*w*3 sums
-  unsigned char* counters = nullptr;      // 16 bytes: segment count, next path
+  unsigned char* counters = nullptr;      // kCounterBytes: segment count, next path, clock stamps
   int32_t* hit_id = nullptr;              // n_rows*w, or nullptr
   uint8_t* rgb = nullptr;                 // n_rows*w*3
 };
@@ -487,7 +488,7 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   p.n_waves = (uint32_t)grid * (rtow::kTraceThreads / 64);
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(hipMemsetAsync(t.counters, 0, 16, c->stream));
+  HIP_TRY(hipMemsetAsync(t.counters, 0, kCounterBytes, c->stream));
   if (first_sample == 0 && n_pixels) HIP_TRY(hipMemsetAsync(t.accum, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
   if (n_pixels) rtow::launch_trace(p, grid, c->stream);
@@ -496,7 +497,7 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   rtow::launch_resolve(t.accum, t.rgb, (uint32_t)(3 * n_pixels), first_sample + spp, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  HIP_TRY(hipMemcpyAsync(c->host_counters, t.counters, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->host_counters, t.counters, kCounterBytes, hipMemcpyDeviceToHost, c->stream));
   c->pending = true;
   c->ppm_bytes = 0;
   c->last_w = w; c->last_h = h; c->last_spp = spp; c->last_rows = n_rows;
@@ -584,6 +585,10 @@ int rtow_sync(rtow_ctx* c) {
     c->stats.paths = (uint64_t)c->last_rows * (uint64_t)c->last_w * (uint64_t)c->last_spp;
     c->stats.n_spheres = c->n_spheres;
     c->stats.n_big = c->n_big;
+    {
+      const uint64_t ticks = c->host_counters[4] - c->host_counters[2], ref = c->host_counters[5] - c->host_counters[3];
+      c->stats.shader_clock_mhz = ref > 0 && c->host_counters[5] > c->host_counters[3] ? (float)((double)ticks / (double)ref * 100.0) : 0.0f;
+    }
     HIP_TRY(hipEventElapsedTime(&c->stats.trace_ms, c->ev[1], c->ev[2]));
     HIP_TRY(hipEventElapsedTime(&c->stats.total_ms, c->ev[0], c->ev[3]));
   }

@@ -40,7 +40,8 @@ struct TraceParams {
   unsigned long long* path_counter; // next path to hand out; zeroed before launch
   unsigned long long* accum;        // n_rows*W*3 fixed-point sums, zeroed before launch
   int32_t* hit_id;                  // n_rows*W or nullptr
-  unsigned long long* seg_counter;  // zeroed before launch
+  unsigned long long* seg_counter;  // zeroed before launch; [2..5] receive the first wave's clock stamps:
+                                    // shader clock and constant 100 MHz clock at its start, the same at its end
 };
 
 // rayColor / hit for n caller-given rays, or getRay for n (s, t) pairs: one lane per ray

@@ -655,6 +655,12 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   float my_paths = 0.0f;              // paths this wave has been handed so far
   const float inv_waves = 1.0f / (float)P.n_waves;
   RTOW_PROF_DECL;
+  // the grid's first wave brackets its life - nearly the whole launch - with both clocks, so that the host can
+  // tell what shader clock the chip sustained under this kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    P.seg_counter[2] = __builtin_amdgcn_s_memtime();
+    P.seg_counter[3] = __builtin_amdgcn_s_memrealtime();
+  }
 #ifdef RTOW_PROFILE_TIMELINE
   const uint32_t wave_id = blockIdx.x * (kTraceThreads / 64) + (threadIdx.x >> 6);
   if (lane == 0 && wave_id < 16384) g_wave_times[12 * wave_id] = __builtin_amdgcn_s_memrealtime();
@@ -1011,6 +1017,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   // ray-segment count: wave reduction, one atomic per wave
   const unsigned long long total = nseg_bounce + nseg_primary;
   if (lane == 0) atomicAdd(P.seg_counter, total);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    P.seg_counter[4] = __builtin_amdgcn_s_memtime();
+    P.seg_counter[5] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long long* __restrict__ accum,

@@ -8,6 +8,7 @@ import sys
 
 prof, prefix = sys.argv[1], sys.argv[2]
 lines = []
+alone = []
 trace = os.path.join(prof, "trace", "trace_results.db")
 if os.path.exists(trace):
     c = sqlite3.connect(trace).cursor()
@@ -24,7 +25,6 @@ if os.path.exists(trace):
                           "from kernels where name like '%trace%' order by start"))
     t0 = rows[0][1] if rows else 0
     prev_end = None
-    alone = []
     for k, r in enumerate(rows):
         ov = max(0, prev_end - r[1]) if prev_end is not None else 0
         nxt = rows[k + 1][1] if k + 1 < len(rows) else None
@@ -62,6 +62,11 @@ if all(last(n) is not None for n in need):
     rows.append("")
     rows.append("# derived (last dispatch of the passes)")
     rows.append(f"kernel_cycles,{cycles:.6g}")
+    if alone:   # the un-overlapped launches of the kernel-trace pass of the same command on the same box
+        ms = min(alone) * 1e-6
+        ghz = cycles / (ms * 1e6)
+        rows.append(f"shader_clock_ghz,{ghz:.3f},# kernel_cycles / {ms:.2f} ms (shortest un-overlapped launch of the trace pass); "
+                    f"the 157.3 TFLOP/s peak assumes 2.4 GHz: at this clock it is {157.3 * ghz / 2.4:.1f}")
     rows.append(f"occupancy_waves_per_simd,{4.0 * last('SQ_WAVE_CYCLES') / simd_cycles:.3f},# 4 x SQ_WAVE_CYCLES / (1024 SIMDs x cycles); waves launched: {last('SQ_WAVES'):.0f}")
     rows.append(f"valu_busy_fraction,{4.0 * last('SQ_ACTIVE_INST_VALU') / simd_cycles:.3f},# share of SIMD cycles in which a VALU instruction executes")
     rows.append(f"valu_lane_utilisation,{last('SQ_THREAD_CYCLES_VALU') / (64.0 * last('SQ_ACTIVE_INST_VALU')):.3f},# active lanes per executing VALU instruction / 64 (1 - divergence)")

@@ -70,11 +70,13 @@ def test_spp1_depth1_against_fp64_reference(gpu_renderer, oracle, book_scene):
     R = _R()
     for W, H in ((64, 48), (400, 225), (1200, 800)):
         gpu_renderer.setCamera(R.bookCamera(W / H))
-        rgb, _, hid = gpu_renderer.renderRows(W, H, 1, 1, want_hit_id=True)
-        f_rgb, _, f_hid, f_seg = oracle.render_ref64(arr, n, oracle.book_camera(W / H), W, H, 1, 1, threads=16)
+        rgb, acc, hid = gpu_renderer.renderRows(W, H, 1, 1, want_accum=True, want_hit_id=True)
+        f_rgb, f_acc, f_hid, f_seg = oracle.render_ref64(arr, n, oracle.book_camera(W / H), W, H, 1, 1, threads=16)
         assert (hid == f_hid).all(), f"{W}x{H}: {(hid != f_hid).sum()} of {hid.size} primary hit ids differ"
         assert (rgb == f_rgb).all(), f"{W}x{H}: {(rgb != f_rgb).sum()} of {rgb.size} 8-bit values differ"
         assert gpu_renderer.stats()["ray_segments"] == f_seg == W * H
+        # the sums themselves: the reference's binary64 sky colour cut to 40 fractional bits, 0 where something was hit
+        assert (acc == np.floor(f_acc * 2.0 ** 40).astype(np.uint64)).all()
     # more samples at depth one: every sample is a primary segment, the pixel a sum of binary64 sky colours
     W, H = 400, 225
     gpu_renderer.setCamera(R.bookCamera(W / H))
