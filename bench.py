@@ -32,6 +32,8 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256
 FLOP_PER_TEST = 18             # hitrecord.nim:56-61: oc 3, half_b 5, |oc|^2 5, r*r 1, c 1, disc 3
 FLOP_PER_SEGMENT_EXTRA = 65    # a = |dir|^2 once, hit epilogue, scatter, sky (amortised)
 FLOP_PER_TEST_EXECUTED = 14    # what the kernel's screen really issues per sphere: 7 packed FMAs per pair
+FLOP_PER_SLAB_TEST = 6         # camera rays (one pixel's samples per wave) see a 3-FMA slab test first; about one group of four
+SLAB_PASS_FRACTION = 0.09      # spheres in eleven then goes on to the screen (profiles/: instrumented build, book scene)
 
 WORKLOADS = {
     # name: (width, height, spp, depth, half_extent, lambert_below, metal_below)
@@ -209,6 +211,23 @@ def main():
     trace_ms = [sorted(st["trace_ms"] for st in serial)[1]]  # transients between phases) does not decide
     total_ms = [sorted(st["total_ms"] for st in serial)[1]]
     clock_mhz = sorted(st.get("shader_clock_mhz", 0.0) for st in serial)[1]   # what the chip sustained under the kernel
+    # the same frame on a build of the library without the slab test of the camera rays (librtow_hip_noslab.so,
+    # -DRTOW_NO_SLAB_TEST): every ray-sphere pair then goes through the 7-FMA screen
+    slab_used = True
+    no_slab_ms = None
+    noslab_path = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "librtow_hip_noslab.so")
+    if rank == 0 and os.path.exists(noslab_path):
+        from raytracinginoneweekend_amd import _lib as _L
+        with R.Renderer(device, lib=_L.load(noslab_path)) as plain:
+            plain.setWorld(world_scene)
+            plain.setCamera(R.bookCamera(width / height))
+            ms = []
+            for _ in range(3):
+                plain.renderAsync(width, height, spp, depth, seed, rows=rows)
+                plain.sync()
+                ms.append(plain.stats()["trace_ms"])
+            assert plain.stats()["ray_segments"] == serial[-1]["ray_segments"]
+            no_slab_ms = sorted(ms)[1]
 
     # the frame assembled from all ranks' tiles against the same frame rendered whole on rank 0
     image_verified = None
@@ -273,7 +292,14 @@ def main():
                 # `achieved` counts the reference's work (18 FLOP per ray-sphere test, hitrecord.nim:56-61); the
                 # kernel screens every sphere with 14 FLOP (7 packed FMAs per pair) and runs the full test on
                 # the ~1.2 survivors per ray, so the share of the VALU peak it really issues is lower:
-                "frac_executed_screen_only": serial[-1]["ray_segments"] * FLOP_PER_TEST_EXECUTED * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                # (camera-ray segments - one per path - see the 6-FLOP slab test and the screen for the groups that pass it)
+                "frac_executed_screen_only": (
+                    (serial[-1]["ray_segments"] - (serial[-1]["paths"] if slab_used else 0)) * FLOP_PER_TEST_EXECUTED
+                    + (serial[-1]["paths"] * (FLOP_PER_SLAB_TEST + SLAB_PASS_FRACTION * FLOP_PER_TEST_EXECUTED) if slab_used else 0)
+                ) * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                "slab_test_for_camera_rays": slab_used,
+                "kernel_ms_without_slab_test": no_slab_ms,
+                "frac_without_slab_test": (serial[-1]["ray_segments"] * flop_per_segment / (no_slab_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if no_slab_ms else None,
                 "kernel_ms": avg_trace_s * 1e3,
                 # the peak above is 256 CUs x 256 FLOP/clk at the 2.4 GHz boost clock; under this kernel the chip runs
                 # slower, and differently from box to box.  Clock read by the kernel itself (shader-clock ticks per

@@ -149,8 +149,9 @@ struct rtow_ctx {
   // scene
   bool have_scene = false, have_camera = false;
   int n_spheres = 0, n_geom_pad = 0, n_big = 0;
-  DevBuf geom, geom_rr, geom_nk, geom64, big, shade;
+  DevBuf geom, geom_rr, geom_nk, geom_slab, geom64, big, shade;
   float cmax = 0.0f;
+  float rmax = 0.0f;                          // largest |radius| among the spheres of the binary32 table
   rtow::CameraParams64 cam;
 
   // per-render workspace
@@ -256,7 +257,7 @@ int rtow_destroy(rtow_ctx* c) {
   if (!c) return RTOW_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
+  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom_slab.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release(); c->ray_in.release(); c->ray_out.release(); c->gather.release();
   if (c->gather_host) (void)hipHostFree(c->gather_host);
@@ -350,7 +351,11 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   std::vector<float> nk((size_t)n_alloc, -INFINITY);
   // the scene as given, for the binary64 tests of primary rays; every other table holds binary32 roundings
   std::vector<double4> geom64((size_t)(n > 0 ? n : 1), make_double4(0.0, 0.0, 0.0, 1.0));
-  float cmax = 0.0f;
+  float cmax = 0.0f, rmax = 0.0f;
+  // tables that fit LDS take -k from there, and the last four floats of a group carry -r^2 for the slab test
+  // (+inf, the initial value, for the entries that must never pass)
+  const bool slab_table = n_pad <= rtow::kMaxSpheresKInLds;
+  std::vector<float> slab(slab_table ? 4 : (size_t)n_alloc, INFINITY);   // larger tables: an array of its own
   for (int j = 0; j < n; ++j) {
     geom64[j] = make_double4((double)cx[j], (double)cy[j], (double)cz[j], (double)radius[j]);
     const float fx = (float)cx[j], fy = (float)cy[j], fz = (float)cz[j];
@@ -362,8 +367,11 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
       geom_at(j, 3) = (float)(c2 - (double)r * r);
       exact[j] = make_float4(fx, fy, fz, r * r);
       nk[j] = -geom_at(j, 3);
+      if (slab_table) geom_at(j, 3) = -(r * r);
+      else slab[j] = -(r * r);
       const float reach = (float)std::sqrt(c2) + std::fabs(r);
       if (reach > cmax) cmax = reach;
+      if (std::fabs(r) > rmax) rmax = std::fabs(r);
     }
     if (is_big) {
       rtow::BigSphere b;
@@ -387,12 +395,15 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
+  HIP_TRY(c->geom_slab.reserve(sizeof(float) * slab.size()));
+  HIP_TRY(hipMemcpy(c->geom_slab.p, slab.data(), sizeof(float) * slab.size(), hipMemcpyHostToDevice));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
   HIP_TRY(c->big.reserve(sizeof(rtow::BigSphere) * (big.empty() ? 1 : big.size())));
   HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float) * geom.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->geom_rr.p, exact.data(), sizeof(float4) * exact.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->geom_nk.p, nk.data(), sizeof(float) * nk.size(), hipMemcpyHostToDevice));
   c->cmax = cmax;
+  c->rmax = rmax;
   HIP_TRY(hipMemcpy(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice));
   if (!big.empty())
     HIP_TRY(hipMemcpy(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice));
@@ -456,7 +467,10 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   p.cam = c->cam;
   p.geom = (const float*)c->geom.p; p.geom_exact = (const float4*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
   p.geom64 = (const double4*)c->geom64.p; p.n_list = c->n_spheres;
+  p.geom_slab = (const float*)c->geom_slab.p;
   p.cmax = c->cmax;
+  p.rmax = c->rmax;
+  p.pad_ = 0.0f;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;
   p.W = w; p.H = h; p.spp = spp; p.max_depth = max_depth; p.sample_base = (uint32_t)first_sample;

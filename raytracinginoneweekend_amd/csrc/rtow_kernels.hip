@@ -25,7 +25,8 @@ namespace rtow {
 // rounds of binary32 / binary64 exact tests, [11] passes of the shared rejection loop; clock cycles:
 // [5] hand-out, [1] [2] [13] set-up, scan, shading of PRIMARY iterations, [6] [7] [8] of BOUNCE iterations, [15] all;
 // lanes: [16] BOUNCE segments ending on the sky, [17] [18] [19] hitting a Lambertian / metal / dielectric sphere,
-// [20] lanes still looking for a unit-ball point, summed over those passes, [21] [22] PRIMARY rays missing / hitting, [23] lanes taking a pooled path
+// [20] lanes still looking for a unit-ball point, summed over those passes, [21] [22] PRIMARY rays missing / hitting, [23] lanes taking a pooled path,
+// [24] groups of a PRIMARY scan that pass the slab test
 __device__ unsigned long long g_prof[32];
 
 // wave-local accumulation (values are wave-uniform), flushed once when the wave retires
@@ -111,6 +112,32 @@ static __device__ __forceinline__ f2v pk_fma_bcast(f2v a, f2v b, f2v c) {
   return d;
 }
 
+// Slab test in front of the filter, for scans whose 64 rays are nearly the same ray (the camera rays of a
+// PRIMARY iteration are consecutive samples of one pixel).  The y component of (c - o) x u is the distance
+// between the sphere's centre and the ray's line as seen from above, times |u_xz| <= 1: a sphere the ray
+// hits has |c.z*u.x - c.x*u.z - (o.z*u.x - o.x*u.z)| <= |r|.  Three packed instructions per pair of spheres
+// (two for the value, one for value^2 - r^2) against the filter's seven; a group of four goes on to the
+// filter only if some lane's ray passes, which for 64 samples of one pixel is one group in eleven on the
+// book scene.  `pre` = (o.x*u.z - o.z*u.x, slack); -r^2 of the four spheres comes with the group (+inf
+// for the entries that never pass).  Every ray is still tested against every sphere; the slack is 128
+// times the rounding error of the value (see slab_operands), so the test drops no sphere that is hit.
+static __device__ __forceinline__ f2v pair_slab(const f2v cx, const f2v cz, const f2v nrr, const ScanRay& r, const f2v pre) {
+  f2v t, v, g;
+  // cx * (-u.z) + m : u.z is the low half of r.uzn, m the low half of pre
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cx), "v"(r.uzn), "v"(pre));
+  v = pk_fma_bcast<0, 0>(cz, r.uxy, t);          // + cz * u.x
+  asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(g) : "v"(v), "s"(nrr));   // value^2 - r^2
+  return g;
+}
+
+// (m, slack) of pair_slab for the ray (o, u).  Error of the value evaluated in binary32 on rounded operands:
+// below 2^-21 (|o| + cmax); the test allows delta = 2^-14 (|o|_1 + cmax), i.e. value^2 - r^2 <= delta (2 rmax + delta).
+static __device__ __forceinline__ f2v slab_operands(f3 o, f3 u, float cmax, float rmax) {
+  const float m = fmaf(o.x, u.z, -(o.z * u.x));
+  const float delta = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + cmax) * 0x1p-14f;
+  return f2v{m, delta * fmaf(2.0f, rmax, delta)};
+}
+
 static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -183,6 +210,7 @@ template <bool SHORT> struct WaveLds {
 struct PrimaryCtx {
   lds_f64_ptr rays;
   const double4* geom64;
+  const float* slab;   // -r^2 per table entry for the slab test (tables whose groups have no room for it), else unused
   lds_u32_ptr best_id;
   int n_list;   // entries of geom64 (debug builds check indices against it)
 };
@@ -367,29 +395,41 @@ static __device__ __forceinline__ void cand_drain(CandList<SHORT>& c, ExactPtr e
 struct GroupRec {   // centres of four spheres as packed pairs
   f8v a;            // cx0 cx1 cy0 cy1 cz0 cz1 cx2 cx3
   f4v b;            // cy2 cy3 cz2 cz3
+  f4v nrr;          // -r^2 of the four (loaded only for scans that run the slab test)
 };
 
-template <bool K_LDS>
-static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v& nk) {
+typedef const f4v __attribute__((address_space(4)))* slab_ptr;   // -r^2 of a group's four spheres, one f4v per group
+
+template <bool K_LDS, bool SLAB = false>
+static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v& nk, slab_ptr slab = nullptr) {
   GroupRec r;
   if (K_LDS) {
     typedef const f8v __attribute__((address_space(4)))* p8;
     typedef const f4v __attribute__((address_space(4)))* p4;
     r.a = *(p8)(geom + g);
     r.b = *((p4)(geom + g) + 2);
+    if (SLAB) r.nrr = *((p4)(geom + g) + 3);   // -r^2 of the four spheres (tables whose -k sits in LDS keep it here)
   } else {
     const f16v v = geom[g];
     r.a = v.lo;
     r.b = f4v{v.s8, v.s9, v.sa, v.sb};
     nk = f4v{-v.sc, -v.sd, -v.se, -v.sf};
+    if (SLAB) r.nrr = slab[g];   // these tables use all 16 floats of a group: -r^2 comes from an array of its own
   }
   return r;
 }
 
-template <bool PRIMARY, bool SHORT, typename ExactPtr>
+template <bool PRIMARY, bool SLAB, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v nk, int j, ExactPtr exact,
-                                                  CandList<SHORT>& cand, const ScanRay& r, f3 o, f3 u, float tmin,
+                                                  CandList<SHORT>& cand, const ScanRay& r, const f2v pre, f3 o, f3 u, float tmin,
                                                   int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
+  if (SLAB) {
+    const f2v g0 = pair_slab(grp.a.s01, grp.a.s45, grp.nrr.xy, r, pre);
+    const f2v g1 = pair_slab(grp.a.s67, grp.b.zw, grp.nrr.zw, r, pre);
+    const float mn = fminf(fminf(g0.x, g0.y), fminf(g1.x, g1.y));
+    if (__ballot(mn <= pre.y) == 0) return;   // wave-uniform: no ray of the wave comes near any of the four
+    RTOW_COUNT(24, 1);
+  }
   const f2v f0 = pair_filter(grp.a.s01, grp.a.s23, grp.a.s45, nk.xy, r);
   const f2v f1 = pair_filter(grp.a.s67, grp.b.xy, grp.b.zw, nk.zw, r);
   const float mx = fmaxf(fmaxf(f0.x, f0.y), fmaxf(f1.x, f1.y));
@@ -419,10 +459,18 @@ typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 template <bool PRIMARY, bool K_LDS, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exact, const f4v* nk_lds,
                                                     CandList<SHORT>& cand, int n_groups, float cmax, bool live, f3 o, f3 u,
-                                                    float tmin, int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
+                                                    float tmin, int prev, const PrimaryCtx& pc, f2v pre RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
+  // the slab test runs where the wave's rays are one pixel's camera rays (-DRTOW_NO_SLAB_TEST: a build without
+  // it, every pair goes through the filter - for A/B measurements and the test that it changes nothing)
+#ifdef RTOW_NO_SLAB_TEST
+  constexpr bool SLAB = false;
+#else
+  constexpr bool SLAB = PRIMARY;
+#endif
+  const slab_ptr slab = (slab_ptr)(uintptr_t)pc.slab;
   ScanRay r = scan_ray(o, u, cmax);
-  if (!live) r.ozt.y = INFINITY;
+  if (!live) { r.ozt.y = INFINITY; pre.y = -INFINITY; }
   // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
   // immediate offsets.  (Left to itself the compiler keeps the address in an SGPR and copies it to
   // a VGPR for every read: one more VALU instruction per group.)
@@ -430,14 +478,14 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   asm volatile("" : "+v"(nk_addr));
   nk_lds_ptr nk = (nk_lds_ptr)(uintptr_t)nk_addr;
   f4v ka = K_LDS ? nk[0] : f4v{0, 0, 0, 0}, kb = ka;
-  GroupRec ga = load_group<K_LDS>(geom, 0, ka);
+  GroupRec ga = load_group<K_LDS, SLAB>(geom, 0, ka, slab);
   for (int g = 0; g < n_groups; g += 2) {
-    const GroupRec gb = load_group<K_LDS>(geom, g + 1, kb);
+    const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
     if (K_LDS) kb = nk[1];
-    group_test<PRIMARY>(ga, ka, 4 * g, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
-    ga = load_group<K_LDS>(geom, g + 2, ka);
+    group_test<PRIMARY, SLAB>(ga, ka, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
     if (K_LDS) { ka = nk[2]; nk += 2; }
-    group_test<PRIMARY>(gb, kb, 4 * g + 4, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, SLAB>(gb, kb, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
   }
   cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
@@ -608,6 +656,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   PrimaryCtx pc;
   pc.rays = (lds_f64_ptr)(const double*)pool;
   pc.geom64 = P.geom64;
+  pc.slab = P.geom_slab;
   pc.n_list = P.n_list;
   pc.best_id = (lds_u32_ptr)(wave_lds + L::kIds);
   SumCache sums;
@@ -844,8 +893,12 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         RTOW_COUNT(14, 1);
         RTOW_STAMP(t_scan0);
         // the screen runs on the binary32 roundings of the ray; survivors get the binary64 test
-        if (X_LDS) scan_regular<true, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc RTOW_PROF_ARG);
-        else scan_regular<true, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc RTOW_PROF_ARG);
+        // rmax (the largest radius in the binary32 table) sits behind the camera in the kernel arguments
+        typedef const float __attribute__((address_space(4)))* karg_f32_ptr;
+        static_assert(offsetof(TraceParams, rmax) == sizeof(CameraParams64), "rmax follows the camera");
+        const f2v pre = slab_operands(so, su, P.cmax, ((karg_f32_ptr)cf)[2 * 19]);
+        if (X_LDS) scan_regular<true, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+        else scan_regular<true, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
         RTOW_STAMP(t_scan1);
       }
       // ---- the camera rays' hits: sky ends the path (binary64, raytracer.nim:18-20), a hit scatters
@@ -930,8 +983,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
       if (X_LDS && exhausted && (uint32_t)__popcll(__ballot(alive)) <= kSparseLanes)
         scan_sparse(exact_lds, nk_lds, cand, P.n_geom_pad, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
-      else if (X_LDS) scan_regular<false, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
-      else scan_regular<false, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      else if (X_LDS) scan_regular<false, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
+      else scan_regular<false, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
       RTOW_STAMP(t_scan1);
       // A path that ends adds its radiance to its pixel right away, through the wave's cache of pixel sums
       // (paths that end absorbed or at the depth limit are black and add nothing).
