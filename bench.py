@@ -211,23 +211,19 @@ def main():
     trace_ms = [sorted(st["trace_ms"] for st in serial)[1]]  # transients between phases) does not decide
     total_ms = [sorted(st["total_ms"] for st in serial)[1]]
     clock_mhz = sorted(st.get("shader_clock_mhz", 0.0) for st in serial)[1]   # what the chip sustained under the kernel
-    # the same frame on a build of the library without the slab test of the camera rays (librtow_hip_noslab.so,
-    # -DRTOW_NO_SLAB_TEST): every ray-sphere pair then goes through the 7-FMA screen
-    slab_used = True
+    # the same three steps with the slab test of the camera rays switched off (RTOW_NO_SLAB_TEST is read at every
+    # launch and selects the kernel instance without it): every ray-sphere pair then goes through the 7-FMA screen
+    slab_used = "RTOW_NO_SLAB_TEST" not in os.environ
     no_slab_ms = None
-    noslab_path = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "librtow_hip_noslab.so")
-    if rank == 0 and os.path.exists(noslab_path):
-        from raytracinginoneweekend_amd import _lib as _L
-        with R.Renderer(device, lib=_L.load(noslab_path)) as plain:
-            plain.setWorld(world_scene)
-            plain.setCamera(R.bookCamera(width / height))
-            ms = []
-            for _ in range(3):
-                plain.renderAsync(width, height, spp, depth, seed, rows=rows)
-                plain.sync()
-                ms.append(plain.stats()["trace_ms"])
-            assert plain.stats()["ray_segments"] == serial[-1]["ray_segments"]
-            no_slab_ms = sorted(ms)[1]
+    if slab_used:
+        os.environ["RTOW_NO_SLAB_TEST"] = "1"
+        plain = []
+        for i in range(3):
+            enqueue(i)
+            plain.append(finish(i))
+        del os.environ["RTOW_NO_SLAB_TEST"]
+        assert plain[-1]["ray_segments"] == serial[-1]["ray_segments"]
+        no_slab_ms = sorted(st["trace_ms"] for st in plain)[1]
 
     # the frame assembled from all ranks' tiles against the same frame rendered whole on rank 0
     image_verified = None

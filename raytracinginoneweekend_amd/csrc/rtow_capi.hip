@@ -152,6 +152,7 @@ struct rtow_ctx {
   DevBuf geom, geom_rr, geom_nk, geom_slab, geom64, big, shade;
   float cmax = 0.0f;
   float rmax = 0.0f;                          // largest |radius| among the spheres of the binary32 table
+  int slab_axis = 1;                          // axis of the camera rays' slab test, chosen from the camera
   rtow::CameraParams64 cam;
 
   // per-render workspace
@@ -427,6 +428,14 @@ static int set_camera_f64(rtow_ctx* c, const rtow_camera_f64& cam) {
     c->cam.ver[k] = cam.vertical[k]; c->cam.u[k] = cam.u[k]; c->cam.v[k] = cam.v[k];
   }
   c->cam.lens_radius = cam.lens_radius;
+  {
+    // direction of the ray through the middle of the image; the slab test projects along the axis it has least of
+    double d[3], best = INFINITY;
+    for (int k = 0; k < 3; ++k) d[k] = cam.lower_left[k] + 0.5 * cam.horizontal[k] + 0.5 * cam.vertical[k] - cam.origin[k];
+    c->slab_axis = 1;
+    for (int k = 0; k < 3; ++k)
+      if (std::fabs(d[k]) < best) { best = std::fabs(d[k]); c->slab_axis = k; }
+  }
   c->have_camera = true;
   c->samples_done = 0;              // accumulated samples belong to the previous camera: no pass may continue them
   c->last_row_list_valid = false;
@@ -505,7 +514,13 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   HIP_TRY(hipMemsetAsync(t.counters, 0, kCounterBytes, c->stream));
   if (first_sample == 0 && n_pixels) HIP_TRY(hipMemsetAsync(t.accum, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  if (n_pixels) rtow::launch_trace(p, grid, c->stream);
+  // Camera rays see a slab test along one axis before the filter (rtow_kernels.hip, pair_slab): the axis the
+  // view direction is most perpendicular to.  RTOW_NO_SLAB_TEST switches it off, RTOW_SLAB_AXIS forces an axis
+  // (measurements and tests; the image does not depend on it).
+  int slab_axis = c->slab_axis;
+  if (getenv("RTOW_NO_SLAB_TEST")) slab_axis = -1;
+  else if (const char* e = getenv("RTOW_SLAB_AXIS")) { const int v = atoi(e); if (v >= 0 && v <= 2) slab_axis = v; }
+  if (n_pixels) rtow::launch_trace(p, slab_axis, grid, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   rtow::launch_resolve(t.accum, t.rgb, (uint32_t)(3 * n_pixels), first_sample + spp, c->stream);

@@ -85,7 +85,8 @@ struct ScatterParams {
 };
 void launch_scatter(const ScatterParams& p, hipStream_t stream);
 
-void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream);
+// slab_axis: axis of the slab test the camera rays see before the filter (0, 1, 2; see pair_slab), or -1 for none
+void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);
 int trace_blocks_per_cu(int n_geom_pad);

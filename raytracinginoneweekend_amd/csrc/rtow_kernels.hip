@@ -113,29 +113,44 @@ static __device__ __forceinline__ f2v pk_fma_bcast(f2v a, f2v b, f2v c) {
 }
 
 // Slab test in front of the filter, for scans whose 64 rays are nearly the same ray (the camera rays of a
-// PRIMARY iteration are consecutive samples of one pixel).  The y component of (c - o) x u is the distance
-// between the sphere's centre and the ray's line as seen from above, times |u_xz| <= 1: a sphere the ray
-// hits has |c.z*u.x - c.x*u.z - (o.z*u.x - o.x*u.z)| <= |r|.  Three packed instructions per pair of spheres
-// (two for the value, one for value^2 - r^2) against the filter's seven; a group of four goes on to the
-// filter only if some lane's ray passes, which for 64 samples of one pixel is one group in eleven on the
-// book scene.  `pre` = (o.x*u.z - o.z*u.x, slack); -r^2 of the four spheres comes with the group (+inf
-// for the entries that never pass).  Every ray is still tested against every sphere; the slack is 128
-// times the rounding error of the value (see slab_operands), so the test drops no sphere that is hit.
-static __device__ __forceinline__ f2v pair_slab(const f2v cx, const f2v cz, const f2v nrr, const ScanRay& r, const f2v pre) {
+// PRIMARY iteration are consecutive samples of one pixel).  Component k of (c - o) x u is the distance between
+// the sphere's centre and the ray's line as seen along axis k, times a factor <= 1: a sphere the ray hits has
+//     | c_i u_j - c_j u_i - (o_i u_j - o_j u_i) | <= |r|          (i, j = the two other axes, in cyclic order).
+// Three packed instructions per pair of spheres (two for the value, one for value^2 - r^2) against the
+// filter's seven; a group of four goes on to the filter only if some lane's ray passes, which for 64 samples
+// of one pixel is one group in eleven on the book scene.  The host picks k per launch: the axis the view
+// direction is most perpendicular to (the projection then shortens the rays least).
+// `pre` = (o_j u_i - o_i u_j, slack); -r^2 of the four spheres comes with the group (+inf for the entries that
+// never pass).  Every ray is still tested against every sphere; the slack is 128 times the rounding error of
+// the value (see slab_operands), so the test drops no sphere that is hit.
+template <int AXIS>
+static __device__ __forceinline__ f2v pair_slab(const f2v ci, const f2v cj, const f2v nrr, const ScanRay& r, const f2v pre) {
   f2v t, v, g;
-  // cx * (-u.z) + m : u.z is the low half of r.uzn, m the low half of pre
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cx), "v"(r.uzn), "v"(pre));
-  v = pk_fma_bcast<0, 0>(cz, r.uxy, t);          // + cz * u.x
+  // t = cj * (-u_i) + m, v = ci * u_j + t: u_i and u_j are halves of the pairs the filter already keeps
+  // (r.uxy = u.x, u.y; low half of r.uzn = u.z), m is the low half of pre
+  if (AXIS == 0) {   // i = y, j = z
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(r.uxy), "v"(pre));
+    v = pk_fma_bcast<0, 0>(ci, r.uzn, t);
+  } else if (AXIS == 1) {   // i = z, j = x
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(r.uzn), "v"(pre));
+    v = pk_fma_bcast<0, 0>(ci, r.uxy, t);
+  } else {   // i = x, j = y
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(r.uxy), "v"(pre));
+    v = pk_fma_bcast<1, 0>(ci, r.uxy, t);
+  }
   asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(g) : "v"(v), "s"(nrr));   // value^2 - r^2
   return g;
 }
 
-// (m, slack) of pair_slab for the ray (o, u).  Error of the value evaluated in binary32 on rounded operands:
-// below 2^-21 (|o| + cmax); the test allows delta = 2^-14 (|o|_1 + cmax), i.e. value^2 - r^2 <= delta (2 rmax + delta).
+// pre = (m, slack) of pair_slab for the ray (o, u) and axis AXIS.  Error of the value evaluated in binary32 on
+// rounded operands: below 2^-21 (|o| + cmax); the test allows delta = 2^-14 (|o|_1 + cmax), i.e.
+// value^2 - r^2 <= delta (2 rmax + delta).
+template <int AXIS>
 static __device__ __forceinline__ f2v slab_operands(f3 o, f3 u, float cmax, float rmax) {
-  const float m = fmaf(o.x, u.z, -(o.z * u.x));
+  const float oi = AXIS == 0 ? o.y : AXIS == 1 ? o.z : o.x, oj = AXIS == 0 ? o.z : AXIS == 1 ? o.x : o.y;
+  const float ui = AXIS == 0 ? u.y : AXIS == 1 ? u.z : u.x, uj = AXIS == 0 ? u.z : AXIS == 1 ? u.x : u.y;
   const float delta = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + cmax) * 0x1p-14f;
-  return f2v{m, delta * fmaf(2.0f, rmax, delta)};
+  return f2v{fmaf(oj, ui, -(oi * uj)), delta * fmaf(2.0f, rmax, delta)};
 }
 
 static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
@@ -419,13 +434,16 @@ static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v&
   return r;
 }
 
-template <bool PRIMARY, bool SLAB, bool SHORT, typename ExactPtr>
+template <bool PRIMARY, int AXIS, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v nk, int j, ExactPtr exact,
                                                   CandList<SHORT>& cand, const ScanRay& r, const f2v pre, f3 o, f3 u, float tmin,
                                                   int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
-  if (SLAB) {
-    const f2v g0 = pair_slab(grp.a.s01, grp.a.s45, grp.nrr.xy, r, pre);
-    const f2v g1 = pair_slab(grp.a.s67, grp.b.zw, grp.nrr.zw, r, pre);
+  if (AXIS >= 0) {
+    // coordinates i and j of the four centres, as the pairs the group holds them in
+    const f2v ci0 = AXIS == 0 ? grp.a.s23 : AXIS == 1 ? grp.a.s45 : grp.a.s01, cj0 = AXIS == 0 ? grp.a.s45 : AXIS == 1 ? grp.a.s01 : grp.a.s23;
+    const f2v ci1 = AXIS == 0 ? grp.b.xy : AXIS == 1 ? grp.b.zw : grp.a.s67, cj1 = AXIS == 0 ? grp.b.zw : AXIS == 1 ? grp.a.s67 : grp.b.xy;
+    const f2v g0 = pair_slab<AXIS>(ci0, cj0, grp.nrr.xy, r, pre);
+    const f2v g1 = pair_slab<AXIS>(ci1, cj1, grp.nrr.zw, r, pre);
     const float mn = fminf(fminf(g0.x, g0.y), fminf(g1.x, g1.y));
     if (__ballot(mn <= pre.y) == 0) return;   // wave-uniform: no ray of the wave comes near any of the four
     RTOW_COUNT(24, 1);
@@ -456,18 +474,13 @@ typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 // Called by all 64 lanes of the wave; lanes without a ray pass live = false and offer nothing.  The
 // caller has put every lane's closest hit so far into cand.best (and pc.best_id for a primary scan) and
 // reads the result back from there.
-template <bool PRIMARY, bool K_LDS, bool SHORT, typename ExactPtr>
+template <bool PRIMARY, bool K_LDS, int AXIS, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exact, const f4v* nk_lds,
                                                     CandList<SHORT>& cand, int n_groups, float cmax, bool live, f3 o, f3 u,
                                                     float tmin, int prev, const PrimaryCtx& pc, f2v pre RTOW_PROF_PARAM) {
+  static_assert(AXIS < 0 || PRIMARY, "the slab test is for the camera rays");
   if (n_groups <= 0) return;
-  // the slab test runs where the wave's rays are one pixel's camera rays (-DRTOW_NO_SLAB_TEST: a build without
-  // it, every pair goes through the filter - for A/B measurements and the test that it changes nothing)
-#ifdef RTOW_NO_SLAB_TEST
-  constexpr bool SLAB = false;
-#else
-  constexpr bool SLAB = PRIMARY;
-#endif
+  constexpr bool SLAB = AXIS >= 0;   // the slab test runs where the wave's rays are one pixel's camera rays
   const slab_ptr slab = (slab_ptr)(uintptr_t)pc.slab;
   ScanRay r = scan_ray(o, u, cmax);
   if (!live) { r.ozt.y = INFINITY; pre.y = -INFINITY; }
@@ -482,10 +495,10 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
     if (K_LDS) kb = nk[1];
-    group_test<PRIMARY, SLAB>(ga, ka, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, AXIS>(ga, ka, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
     ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
     if (K_LDS) { ka = nk[2]; nk += 2; }
-    group_test<PRIMARY, SLAB>(gb, kb, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, AXIS>(gb, kb, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
   }
   cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
@@ -638,7 +651,8 @@ static_assert(kPoolFields >= 14, "the pool region also holds seven doubles per l
 // K_LDS: -k per sphere in LDS (tables up to kMaxSpheresKInLds entries).  X_LDS: the records of the
 // exact test (16 bytes per sphere) in LDS as well (tables up to kMaxSpheresExactInLds entries): a
 // round of exact tests then waits for LDS, not for L2, and the survivor list has 16-bit entries.
-template <bool K_LDS, bool X_LDS>
+// SLAB_AXIS: the axis of the slab test that camera rays see before the filter (0, 1, 2), or -1 for none.
+template <bool K_LDS, bool X_LDS, int SLAB_AXIS>
 __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
   // LDS: [4 waves][WaveLds::kTotal], then (K_LDS) -k per sphere, then (X_LDS) the exact-test records
   extern __shared__ f4v lds_raw[];
@@ -896,9 +910,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         // rmax (the largest radius in the binary32 table) sits behind the camera in the kernel arguments
         typedef const float __attribute__((address_space(4)))* karg_f32_ptr;
         static_assert(offsetof(TraceParams, rmax) == sizeof(CameraParams64), "rmax follows the camera");
-        const f2v pre = slab_operands(so, su, P.cmax, ((karg_f32_ptr)cf)[2 * 19]);
-        if (X_LDS) scan_regular<true, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
-        else scan_regular<true, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+        f2v pre = {0.0f, 0.0f};
+        if (SLAB_AXIS >= 0) pre = slab_operands<SLAB_AXIS < 0 ? 0 : SLAB_AXIS>(so, su, P.cmax, ((karg_f32_ptr)cf)[2 * 19]);
+        if (X_LDS) scan_regular<true, K_LDS, SLAB_AXIS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+        else scan_regular<true, K_LDS, SLAB_AXIS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
         RTOW_STAMP(t_scan1);
       }
       // ---- the camera rays' hits: sky ends the path (binary64, raytracer.nim:18-20), a hit scatters
@@ -983,8 +998,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
       if (X_LDS && exhausted && (uint32_t)__popcll(__ballot(alive)) <= kSparseLanes)
         scan_sparse(exact_lds, nk_lds, cand, P.n_geom_pad, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
-      else if (X_LDS) scan_regular<false, K_LDS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
-      else scan_regular<false, K_LDS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
+      else if (X_LDS) scan_regular<false, K_LDS, -1>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
+      else scan_regular<false, K_LDS, -1>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
       RTOW_STAMP(t_scan1);
       // A path that ends adds its radiance to its pixel right away, through the wave's cache of pixel sums
       // (paths that end absorbed or at the depth limit are black and add nothing).
@@ -1091,15 +1106,25 @@ static size_t kx_lds_bytes(int n_geom_pad) {
   return wave_lds_bytes(true) + sizeof(float) * (size_t)(n_geom_pad + 4) + sizeof(float4) * (size_t)n_geom_pad;
 }
 
-void launch_trace(const TraceParams& p, int grid_blocks, hipStream_t stream) {
+template <int SLAB_AXIS>
+static void launch_trace_axis(const TraceParams& p, int grid_blocks, hipStream_t stream) {
   if (p.n_geom_pad <= kMaxSpheresExactInLds)
-    hipLaunchKernelGGL((rtow_trace_kernel<true, true>), dim3(grid_blocks), dim3(kTraceThreads), kx_lds_bytes(p.n_geom_pad),
+    hipLaunchKernelGGL((rtow_trace_kernel<true, true, SLAB_AXIS>), dim3(grid_blocks), dim3(kTraceThreads), kx_lds_bytes(p.n_geom_pad),
                        stream, p);
   else if (p.n_geom_pad <= kMaxSpheresKInLds)
-    hipLaunchKernelGGL((rtow_trace_kernel<true, false>), dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
+    hipLaunchKernelGGL((rtow_trace_kernel<true, false, SLAB_AXIS>), dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
                        stream, p);
   else
-    hipLaunchKernelGGL((rtow_trace_kernel<false, false>), dim3(grid_blocks), dim3(kTraceThreads), wave_lds_bytes(false), stream, p);
+    hipLaunchKernelGGL((rtow_trace_kernel<false, false, SLAB_AXIS>), dim3(grid_blocks), dim3(kTraceThreads), wave_lds_bytes(false), stream, p);
+}
+
+void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStream_t stream) {
+  switch (slab_axis) {
+    case 0: launch_trace_axis<0>(p, grid_blocks, stream); break;
+    case 1: launch_trace_axis<1>(p, grid_blocks, stream); break;
+    case 2: launch_trace_axis<2>(p, grid_blocks, stream); break;
+    default: launch_trace_axis<-1>(p, grid_blocks, stream); break;
+  }
 }
 
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
@@ -1443,11 +1468,11 @@ int trace_blocks_per_cu(int n_geom_pad) {
   int nb = 0;
   hipError_t e;
   if (n_geom_pad <= kMaxSpheresExactInLds)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, true>, kTraceThreads, kx_lds_bytes(n_geom_pad));
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, true, 1>, kTraceThreads, kx_lds_bytes(n_geom_pad));
   else if (n_geom_pad <= kMaxSpheresKInLds)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, false>, kTraceThreads, k_lds_bytes(n_geom_pad));
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, false, 1>, kTraceThreads, k_lds_bytes(n_geom_pad));
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false, false>, kTraceThreads, wave_lds_bytes(false));
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false, false, 1>, kTraceThreads, wave_lds_bytes(false));
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }

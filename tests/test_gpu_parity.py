@@ -591,18 +591,15 @@ def test_table_sizes_around_the_lds_thresholds(oracle):
             assert r.stats()["ray_segments"] == ref[3], n
 
 
-def test_slab_test_of_camera_rays_changes_nothing(oracle):
-    """Camera rays see a 3-FMA slab test before the 7-FMA screen.  It may only drop spheres the ray misses: a build
-    of the library without it (librtow_hip_noslab.so) gives the same hit ids, sums and segment counts - on the book
-    scene, with the camera looking straight down and straight up (the test's projection degenerates), from
-    inside a glass sphere, on a vertical stack of spheres, on a table beyond the LDS sizes - and both equal the
-    mirror, which has no such test."""
-    from conftest import ROOT
-    from raytracinginoneweekend_amd import _lib
+def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
+    """Camera rays see a 3-FMA slab test before the 7-FMA screen, along the axis the host picks from the camera.
+    It may only drop spheres the ray misses: without it (RTOW_NO_SLAB_TEST, read at every launch) and along each
+    of the three axes (RTOW_SLAB_AXIS) hit ids, sums and segment counts are the same - on the book scene, with
+    the camera looking straight down and straight up (a projection degenerates), from inside a glass sphere, on a
+    vertical stack of spheres, on a table beyond the LDS sizes - and equal the mirror, which has no such test."""
     from raytracinginoneweekend_amd.basetypes import point, vec3
     from raytracinginoneweekend_amd.camera import initCamera
     R = _R()
-    plain_lib = _lib.load(os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "librtow_hip_noslab.so"))
     W, H, spp, depth = 160, 100, 3, 50
     stack = {"center_x": [0.0] * 40 + [0.0], "center_y": [0.5 * k for k in range(40)] + [-1000.0], "center_z": [0.0] * 40 + [0.0],
              "radius": [0.3] * 40 + [1000.0], "kind": [k % 3 for k in range(40)] + [0], "albedo": np.full((41, 3), 0.7),
@@ -618,19 +615,20 @@ def test_slab_test_of_camera_rays_changes_nothing(oracle):
         (stack, o_stack, dict(look_from=(6, 10, 4), look_at=(0, 9, 0), vfov=60.0, aperture=0.3, focus=7.0)),
         (R.randomScene(halfExtent=35), oracle.random_scene(half_extent=35)[:2], book),
     ]
-    with R.Renderer(0) as r, R.Renderer(0, lib=plain_lib) as plain:
+    with R.Renderer(0) as r:
         for world, (arr, n), cam in cases:
-            camera = initCamera(point(*cam["look_from"]), point(*cam["look_at"]), vec3(0, 1, 0), vfov=cam["vfov"],
-                                aspectRatio=W / H, aperture=cam["aperture"], focusDist=cam["focus"])
-            out = []
-            for dev in (r, plain):
-                dev.setWorld(world)
-                dev.setCamera(camera)
-                out.append(dev.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True) + (dev.stats()["ray_segments"],))
-            on, off = out
-            assert (on[2] == off[2]).all() and (on[1] == off[1]).all() and (on[0] == off[0]).all() and on[3] == off[3]
+            r.setWorld(world)
+            r.setCamera(initCamera(point(*cam["look_from"]), point(*cam["look_at"]), vec3(0, 1, 0), vfov=cam["vfov"],
+                                   aspectRatio=W / H, aperture=cam["aperture"], focusDist=cam["focus"]))
             ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H, **cam), W, H, spp, depth, threads=16)
-            _check_bit_exact(on[:3], ref)
+            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}, {"RTOW_SLAB_AXIS": "0"}, {"RTOW_SLAB_AXIS": "1"}, {"RTOW_SLAB_AXIS": "2"}):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+                for k in env:
+                    monkeypatch.delenv(k)
+                _check_bit_exact(got, ref)
+                assert r.stats()["ray_segments"] == ref[3], env
 
 
 def test_smallest_frame_and_depth_one(oracle, book_scene):
