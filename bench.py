@@ -201,16 +201,24 @@ def main():
 
     # one frame at a time, for the kernel's own duration (launches that overlap stretch each other)
     # and for the latency of a single step
+    def note(msg):   # long configurations: a line per phase, so that a watcher sees the run is alive
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"timed region done: {elapsed / max(1, args.steps) * 1e3:.1f} ms per step")
+    n_serial = 3 if elapsed / max(1, args.steps) < 2.0 else 1     # frames of many seconds: one is enough
+    mid = n_serial // 2
     serial, serial_wall = [], []
-    for i in range(3):
+    for i in range(n_serial):
         t1 = time.perf_counter()
         enqueue(i)
         serial.append(finish(i))
         serial_wall.append((time.perf_counter() - t1) * 1e3)
-    serial_ms = sorted(serial_wall)[1]                      # medians of three: one slow launch (clock
-    trace_ms = [sorted(st["trace_ms"] for st in serial)[1]]  # transients between phases) does not decide
-    total_ms = [sorted(st["total_ms"] for st in serial)[1]]
-    clock_mhz = sorted(st.get("shader_clock_mhz", 0.0) for st in serial)[1]   # what the chip sustained under the kernel
+        note(f"serial step {i + 1} of {n_serial}")
+    serial_ms = sorted(serial_wall)[mid]                      # medians of three: one slow launch (clock
+    trace_ms = [sorted(st["trace_ms"] for st in serial)[mid]]  # transients between phases) does not decide
+    total_ms = [sorted(st["total_ms"] for st in serial)[mid]]
+    clock_mhz = sorted(st.get("shader_clock_mhz", 0.0) for st in serial)[mid]   # what the chip sustained under the kernel
     # the same three steps with the slab test of the camera rays switched off (RTOW_NO_SLAB_TEST is read at every
     # launch and selects the kernel instance without it): every ray-sphere pair then goes through the 7-FMA screen
     slab_used = "RTOW_NO_SLAB_TEST" not in os.environ
@@ -218,17 +226,18 @@ def main():
     if slab_used:
         os.environ["RTOW_NO_SLAB_TEST"] = "1"
         plain = []
-        for i in range(3):
+        for i in range(n_serial):
             enqueue(i)
             plain.append(finish(i))
+            note(f"step {i + 1} of {n_serial} without the slab test")
         del os.environ["RTOW_NO_SLAB_TEST"]
         assert plain[-1]["ray_segments"] == serial[-1]["ray_segments"]
-        no_slab_ms = sorted(st["trace_ms"] for st in plain)[1]
+        no_slab_ms = sorted(st["trace_ms"] for st in plain)[mid]
 
     # the frame assembled from all ranks' tiles against the same frame rendered whole on rank 0
     image_verified = None
     if world > 1 and rank == 0:
-        last = gatherers[2 % depth_in_flight].full          # gathered by the last serial step
+        last = gatherers[(n_serial - 1) % depth_in_flight].full          # gathered by the last step
         whole = renderers[0].renderRows(width, height, spp, depth, seed)[0]
         image_verified = bool((last.cpu().numpy() == whole).all())
 

@@ -138,8 +138,8 @@ static __device__ __forceinline__ f2v pair_slab(const f2v ci, const f2v cj, cons
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(r.uxy), "v"(pre));
     v = pk_fma_bcast<1, 0>(ci, r.uxy, t);
   }
-  asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(g) : "v"(v), "s"(nrr));   // value^2 - r^2
-  return g;
+  g = __builtin_elementwise_fma(v, v, nrr);   // value^2 - r^2 (left to the compiler: it then knows the result is no signalling NaN
+  return g;                                   // and does not quiet it again before taking the minimum)
 }
 
 // pre = (m, slack) of pair_slab for the ray (o, u) and axis AXIS.  Error of the value evaluated in binary32 on
@@ -434,8 +434,12 @@ static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v&
   return r;
 }
 
-template <bool PRIMARY, int AXIS, bool SHORT, typename ExactPtr>
-static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v nk, int j, ExactPtr exact,
+typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
+
+// nk: -k of the four spheres, or (NK_LATE) nk_late points at them in LDS and they are fetched only if the group
+// gets as far as the filter
+template <bool PRIMARY, int AXIS, bool NK_LATE, bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void group_test(const GroupRec grp, f4v nk, nk_lds_ptr nk_late, int j, ExactPtr exact,
                                                   CandList<SHORT>& cand, const ScanRay& r, const f2v pre, f3 o, f3 u, float tmin,
                                                   int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
   if (AXIS >= 0) {
@@ -447,6 +451,7 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v 
     const float mn = fminf(fminf(g0.x, g0.y), fminf(g1.x, g1.y));
     if (__ballot(mn <= pre.y) == 0) return;   // wave-uniform: no ray of the wave comes near any of the four
     RTOW_COUNT(24, 1);
+    if (NK_LATE) nk = *nk_late;
   }
   const f2v f0 = pair_filter(grp.a.s01, grp.a.s23, grp.a.s45, nk.xy, r);
   const f2v f1 = pair_filter(grp.a.s67, grp.b.xy, grp.b.zw, nk.zw, r);
@@ -469,7 +474,6 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, const f4v 
 // start as fma(cx, 2o.x, -k): a VALU instruction can read only one SGPR operand, so with k in an
 // SGPR the subtraction would cost a packed instruction of its own.  Tables too large for LDS use
 // the SGPR copy of k (moved to VGPRs first; same arithmetic, two more instructions per group).
-typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 
 // Called by all 64 lanes of the wave; lanes without a ray pass live = false and offer nothing.  The
 // caller has put every lane's closest hit so far into cand.best (and pc.best_id for a primary scan) and
@@ -490,15 +494,18 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   uint32_t nk_addr = K_LDS ? (uint32_t)(uintptr_t)(nk_lds_ptr)nk_lds : 0u;
   asm volatile("" : "+v"(nk_addr));
   nk_lds_ptr nk = (nk_lds_ptr)(uintptr_t)nk_addr;
-  f4v ka = K_LDS ? nk[0] : f4v{0, 0, 0, 0}, kb = ka;
+  // with the slab test in front, one group in eleven needs its -k: it is read then, not one group ahead
+  constexpr bool NK_LATE = SLAB && K_LDS;
+  f4v ka = (K_LDS && !NK_LATE) ? nk[0] : f4v{0, 0, 0, 0}, kb = ka;
   GroupRec ga = load_group<K_LDS, SLAB>(geom, 0, ka, slab);
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
-    if (K_LDS) kb = nk[1];
-    group_test<PRIMARY, AXIS>(ga, ka, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    if (K_LDS && !NK_LATE) kb = nk[1];
+    group_test<PRIMARY, AXIS, NK_LATE>(ga, ka, nk, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
     ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
-    if (K_LDS) { ka = nk[2]; nk += 2; }
-    group_test<PRIMARY, AXIS>(gb, kb, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    if (K_LDS && !NK_LATE) ka = nk[2];
+    group_test<PRIMARY, AXIS, NK_LATE>(gb, kb, nk + 1, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    if (K_LDS) nk += 2;
   }
   cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }

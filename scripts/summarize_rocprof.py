@@ -24,19 +24,25 @@ if os.path.exists(trace):
     rows = list(c.execute("select name,start,end,duration,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size "
                           "from kernels where name like '%trace%' order by start"))
     t0 = rows[0][1] if rows else 0
+    main = rows[0][0] if rows else ""   # the instance the timed region runs; bench.py ends with a few launches of the instance without the slab test
     prev_end = None
+    others = {}
     for k, r in enumerate(rows):
         ov = max(0, prev_end - r[1]) if prev_end is not None else 0
         nxt = rows[k + 1][1] if k + 1 < len(rows) else None
         if ov == 0 and (nxt is None or nxt >= r[2]):
-            alone.append(r[3])
+            (alone if r[0] == main else others.setdefault(r[0], [])).append(r[3])
         prev_end = r[2]
         lines.append(",".join(str(x) for x in (r[0], r[1] - t0, r[3], ov) + tuple(r[4:])))
     if alone:
-        lines.append(f"# launches that ran alone: {len(alone)}, average duration {sum(alone) / len(alone):.0f} ns")
+        lines.append(f"# launches of {main} that ran alone: {len(alone)}, average duration {sum(alone) / len(alone):.0f} ns")
+    for name, d in others.items():
+        lines.append(f"# launches of {name} that ran alone: {len(d)}, average duration {sum(d) / len(d):.0f} ns")
 open(prefix + "_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
 
 pmc = {}
+pmc_other = {}
+main_pmc = None
 for db in sorted(glob.glob(os.path.join(prof, "pmc_*", "pmc_results.db"))):
     c = sqlite3.connect(db).cursor()
     q = ("select kernel_name, dispatch_id, counter_name, sum(value) from counters_collection "
@@ -44,11 +50,22 @@ for db in sorted(glob.glob(os.path.join(prof, "pmc_*", "pmc_results.db"))):
     for name, disp, counter, value in c.execute(q):
         if "trace" not in name:
             continue
+        if main_pmc is None:
+            main_pmc = name           # the first trace dispatch of a pass: the instance the timed region runs
+        if name != main_pmc:          # the instance without the slab test, launched at the end of bench.py
+            pmc_other.setdefault(counter, []).append(value)
+            continue
         pmc.setdefault(counter, []).append(value)
-rows = ["# rocprofv3 --pmc passes, rtow_trace_kernel, one value per dispatch (sum over XCDs/SEs)",
+rows = [f"# rocprofv3 --pmc passes, {main_pmc}, one value per dispatch (sum over XCDs/SEs)",
         "counter,per_dispatch_values"]
 for k in sorted(pmc):
     rows.append(k + "," + " ".join(f"{v:.6g}" for v in pmc[k]))
+if pmc_other:
+    rows.append("")
+    rows.append("# the same counters for the launches of the instance without the slab test (end of bench.py)")
+    for k in sorted(pmc_other):
+        rows.append(k + "," + " ".join(f"{v:.6g}" for v in pmc_other[k]))
+    rows.append("")
 # figures derived from the LAST dispatch of each pass (a launch that ran alone).  SQ counters count quad-cycles
 # summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs.
 def last(name):
