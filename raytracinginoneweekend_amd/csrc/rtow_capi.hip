@@ -489,7 +489,7 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   // full frame and 4 % on a 1/8 share, where the end of the frame weighs more - and 128 or less pay for
   // the chunk-to-pixel arithmetic (about 250 instructions per chunk).
   p.chunk_max = 256;
-  p.chunk_min = 192; p.total_paths = total_paths;
+  p.chunk_min = 256; p.total_paths = total_paths;
   if (const char* e = getenv("RTOW_CHUNK_MAX")) {  // experiments only: multiples of 64
     const int v = atoi(e);
     if (v >= 64 && v <= 65536 && v % 64 == 0) p.chunk_max = (uint32_t)v;
