@@ -1,18 +1,24 @@
 // gfx950 kernels of the renderer.
 //
 //  rtow_trace_kernel   persistent waves; every lane carries one path (pixel, sample) through an
-//                      iterative bounce loop and is refilled with a new path the moment its
-//                      path ends, so the sphere scan always runs with full wavefronts.  Work is
-//                      handed out in chunks (runs of consecutive paths, pixel-major) from a global
-//                      counter, in sizes that shrink as the frame runs out.  Radiance is summed per lane in
-//                      64-bit fixed point; a lane that moves on to another pixel adds its sums
-//                      (through a small per-wave cache in LDS) to the frame with integer atomics,
-//                      which makes the image independent of scheduling, chunking and GPU count.
+//                      iterative bounce loop.  A wave alternates between iterations that start 64 new
+//                      paths (camera ray and first hit in binary64, as the reference computes them) and
+//                      iterations that trace the next binary32 segment of the paths in flight, idle
+//                      lanes taking scattered paths from a per-wave pool in LDS first, so every sphere
+//                      scan runs with full wavefronts.  Work is handed out in chunks (runs of
+//                      consecutive paths, pixel-major) from a global counter.  The radiance of a path
+//                      that ends is added in 64-bit fixed point (through a small per-wave cache in LDS)
+//                      to the frame with integer atomics, which makes the image independent of
+//                      scheduling, chunking and GPU count.
 //  rtow_resolve_kernel mean + sqrt gamma + clamp + 8-bit quantisation (raytracer.nim:22-28).
 //
 // The sphere scan (hittables.nim:79-88 over hitrecord.nim:55-63) keeps the ray in VGPRs and
 // streams the sphere table through SGPRs with wave-uniform scalar loads, four spheres per load,
-// two spheres per packed FP32 instruction, and a rarely taken branch for discriminant >= 0.
+// two spheres per packed FP32 instruction, and a rarely taken branch for discriminant >= 0; camera
+// rays - 64 samples of one pixel per wave - see a cheaper slab test first.
+//  rtow_rays_kernel, rtow_get_rays_kernel, rtow_scatter_kernel   the reference's per-ray procs (rayColor / hit,
+//                      getRay, scatter) for batches of caller-given rays, one lane per ray.
+//  ppm_*_kernel        the P3 text of the image, composed on the device.
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include "rtow_kernels.h"
