@@ -313,3 +313,54 @@ def test_mirror_scatter_tracks_the_fp64_scatter(oracle):
         kinds[kind] += 1
         assert np.allclose(list(a32), list(a64), rtol=1e-6, atol=0)
     assert other <= 3 and min(kinds) > 300
+
+
+def test_slab_test_of_camera_rays_is_conservative():
+    """The renderer puts a three-FMA slab test in front of the sphere screen for camera rays: component k of
+    (c - o) x u, evaluated in binary32 on rounded operands, against |r| with the slack delta (2 rmax + delta),
+    delta = 2^-14 (|o|_1 + cmax).  Restated here in numpy (binary32 operations, fused where the kernel fuses) and
+    held against the exact geometry in binary64: no sphere whose line distance is within its radius may fail,
+    along any axis, for near and far cameras and small and large scenes; the worst case must leave most of the
+    slack unused."""
+    import numpy as np
+    f32 = np.float32
+
+    def fma32(a, b, c):   # a * b is exact in binary64; one rounding to binary64 before the one to binary32 is harmless here
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+
+    rng = np.random.default_rng(9)
+    worst = 0.0
+    for spread, cam_dist, rad in ((11.0, 14.0, 0.2), (11.0, 300.0, 0.2), (200.0, 50.0, 3.0), (1.0, 2.0, 0.05), (30.0, 5000.0, 20.0)):
+        n = 400
+        c64 = np.column_stack([rng.uniform(-spread, spread, n), rng.uniform(0, 0.3 * spread, n), rng.uniform(-spread, spread, n)])
+        r64 = rad * np.exp(rng.uniform(-1, 1, n)) * rng.choice([1.0, -1.0], n)
+        cmax = f32((np.linalg.norm(c64.astype(f32).astype(np.float64), axis=1) + np.abs(r64)).max())
+        rmax = f32(np.abs(r64).max())
+        m = 3000
+        o64 = rng.normal(0, 1, (m, 3)); o64 *= cam_dist / np.linalg.norm(o64, axis=1, keepdims=True)
+        target = c64[rng.integers(0, n, m)] + rng.normal(0, 1, (m, 3)) * np.abs(r64).mean()   # aim near spheres: many grazing rays
+        d64 = (target - o64) * np.exp(rng.uniform(-2, 2, (m, 1)))
+        # exact geometry: distance from the centre to the ray's line
+        u64 = d64 / np.linalg.norm(d64, axis=1, keepdims=True)
+        oc = c64[None, :, :] - o64[:, None, :]
+        dist = np.linalg.norm(np.cross(oc, u64[:, None, :]), axis=2)
+        hit = dist <= np.abs(r64)[None, :]
+        # the kernel's operands: rounded origin, direction normalised in binary32, rounded centres and radii
+        o = o64.astype(f32); d = d64.astype(f32)
+        inv = (f32(1.0) / np.sqrt(fma32(d[:, 2], d[:, 2], fma32(d[:, 1], d[:, 1], d[:, 0] * d[:, 0])))).astype(f32)
+        u = (d * inv[:, None]).astype(f32)
+        c = c64.astype(f32); r = r64.astype(f32)
+        delta = ((np.abs(o[:, 0]) + np.abs(o[:, 1]) + np.abs(o[:, 2]) + cmax) * f32(2.0 ** -14)).astype(f32)
+        slack = (delta * fma32(np.full(m, 2.0, f32), np.full(m, rmax, f32), delta)).astype(f32)
+        for axis in range(3):
+            i, j = (axis + 1) % 3, (axis + 2) % 3
+            mm = fma32(o[:, j], u[:, i], -(o[:, i] * u[:, j]).astype(f32))
+            t = fma32(np.broadcast_to(c[None, :, j], (m, n)), np.broadcast_to(-u[:, None, i], (m, n)), np.broadcast_to(mm[:, None], (m, n)))
+            v = fma32(np.broadcast_to(c[None, :, i], (m, n)), np.broadcast_to(u[:, None, j], (m, n)), t)
+            g = fma32(v, v, np.broadcast_to(-(r * r).astype(f32)[None, :], (m, n)))
+            passes = g <= slack[:, None]
+            assert passes[hit].all(), (spread, cam_dist, axis, int((~passes[hit]).sum()))
+            used = (g[hit] / np.broadcast_to(slack[:, None], (m, n))[hit]).max()   # > 0 only where rounding ate into the slack
+            worst = max(worst, float(used))
+        assert hit.sum() > 2000
+    assert worst < 0.1, worst   # the slack is at least ten times what rounding takes
