@@ -90,6 +90,43 @@ def cpu_baseline(width, height, depth, seed):
     }
 
 
+def launch_workers(n_gpus):
+    """Run this script as n_gpus worker processes (one per GPU) under torch.distributed.run and relay the
+    result: rank 0's JSON line goes to stdout, everything else the workers print to stderr.  Returns the
+    exit status of the launcher.  The calling process must not have initialised the GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    n_lines = 0
+    for line in proc.stdout:
+        text = line.strip()
+        is_result = False
+        if text.startswith("{"):
+            try:
+                is_result = "metric" in json.loads(text)
+            except ValueError:
+                is_result = False
+        if is_result:
+            n_lines += 1
+            print(text, flush=True)
+        elif text:
+            print(text, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and n_lines != 1:
+        print(f"bench.py: the workers exited normally but printed {n_lines} result lines", file=sys.stderr)
+        return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,12 +141,16 @@ def main():
                          "(ranks share devices, rows are gathered through host memory); not a valid benchmark")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Plain `python bench.py --gpus N`: this process becomes the launcher.  It starts one worker per GPU through
+        # torch.distributed.run, passes rank 0's JSON line on and exits with the workers' status.  Nothing here has
+        # touched a GPU or imported torch, and nothing is exec'ed: the workers are fresh child processes.
+        raise SystemExit(launch_workers(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one process per GPU)")
         args.gpus = world
 
     width, height, spp, depth, half_extent, lam, met = WORKLOADS[args.workload]

@@ -11,10 +11,12 @@ proc check(status: cint, what: string) =
 
 type Flat = object
   cx, cy, cz, rad, albedo, fuzz, ir: seq[cdouble]
-  kind: seq[uint8]
+  kind: seq[uint8]                        # MaterialKind of each sphere
+  hkind: seq[uint8]                       # Hittable.kind of each entry (hittables.nim:6)
 
 proc flatten(world: var HittablesList): Flat =
   for obj in world:                       # list order is kept: it decides ties (hittables.nim:84-88)
+    result.hkind.add obj.kind.ord.uint8
     let s = obj.hSphere
     result.cx.add s.center.x; result.cy.add s.center.y; result.cz.add s.center.z
     result.rad.add s.radius
@@ -32,11 +34,14 @@ proc flatten(world: var HittablesList): Flat =
 
 template p(s: seq[cdouble]): ptr cdouble = (if s.len > 0: unsafeAddr s[0] else: nil)
 
-proc upload(ctx: RtowCtx, world: var HittablesList) =
-  let f = flatten(world)
+proc upload(ctx: RtowCtx, f: Flat) =
   let kinds = if f.kind.len > 0: unsafeAddr f.kind[0] else: nil   # an empty world is legal: every ray sees the sky
-  check rtow_set_scene_f64(ctx, f.rad.len.cint, p(f.cx), p(f.cy), p(f.cz), p(f.rad), kinds, p(f.albedo), p(f.fuzz), p(f.ir)),
-        "rtow_set_scene_f64"
+  let hkinds = if f.hkind.len > 0: unsafeAddr f.hkind[0] else: nil
+  # the list with its Hittable kinds: the library, like hit*(h: Hittable) (hittables.nim:75-77), knows htSphere only
+  check rtow_set_hittables(ctx, f.rad.len.cint, hkinds, p(f.cx), p(f.cy), p(f.cz), p(f.rad), kinds, p(f.albedo), p(f.fuzz),
+                           p(f.ir)), "rtow_set_hittables"
+
+proc upload(ctx: RtowCtx, world: var HittablesList) = upload(ctx, flatten(world))
 
 proc render*(img: Image, f: string, world: var HittablesList, camera: Camera,
              samplesPerPixel, maxDepth: int, seed: uint64 = 0xE7) =
@@ -55,10 +60,12 @@ proc render*(img: Image, f: string, world: var HittablesList, camera: Camera,
   check rtow_format_ppm(ctx, 0, text.cstring, length, addr length), "rtow_format_ppm"
   writeFile(f, text)
 
-# ---- per-ray procs: a context is kept per thread, the world / camera are uploaded again when they change
+# ---- per-ray procs: a context is kept per thread.  The reference's procs see the CURRENT contents of their
+# `var HittablesList`, so the list is flattened on every call and uploaded again whenever the values differ from
+# what the device holds (a sphere edited in place at the same length counts); one-ray slow paths anyway.
 var gCtx {.threadvar.}: RtowCtx
-var gWorldLen {.threadvar.}: int
-var gWorldData {.threadvar.}: pointer
+var gWorld {.threadvar.}: Flat
+var gWorldValid {.threadvar.}: bool
 
 proc device(): RtowCtx =
   if gCtx.pointer == nil: check rtow_create(0, addr gCtx), "rtow_create"
@@ -66,9 +73,11 @@ proc device(): RtowCtx =
 
 proc deviceWith(world: var HittablesList): RtowCtx =
   result = device()
-  if gWorldData != cast[pointer](addr world) or gWorldLen != world.len:
-    upload(result, world)
-    gWorldData = cast[pointer](addr world); gWorldLen = world.len
+  let f = flatten(world)
+  if not gWorldValid or f != gWorld:
+    gWorldValid = false
+    upload(result, f)
+    gWorld = f; gWorldValid = true
 
 proc rayColor*(r: Ray, world: var HittablesList, depth: int): Color =
   let ctx = deviceWith(world)
@@ -92,6 +101,17 @@ proc hit*(h: var HittablesList, r: Ray, t_min, t_max: float, rec: var HitRecord)
   rec.setFaceNormal(r, (rec.p - s.center) / s.radius)      # hitrecord.nim:73-77
   rec.mat = s.mat
   true
+
+proc hit*(s: Sphere, r: Ray, t_min, t_max: float, rec: var HitRecord): bool =
+  ## hitrecord.nim:55-79: one sphere is a one-entry list
+  var one = initHittables(0)
+  one.add s
+  hit(one, r, t_min, t_max, rec)
+
+proc hit*(h: Hittable, r: Ray, t_min, t_max: float, rec: var HitRecord): bool =
+  ## hittables.nim:75-77
+  case h.kind
+  of htSphere: result = h.hSphere.hit(r, t_min, t_max, rec)
 
 proc scatter*(m: Material, r_in: Ray, rec: HitRecord, attenuation: var Color, scattered: var Ray): bool =
   ## hitrecord.nim:127-132; draws from the stream of path (pixel 0, sample 0) instead of the global generator

@@ -11,13 +11,18 @@ type
     raySegments*, paths*: uint64
     traceMs*, totalMs*: cfloat
     nSpheres*, nBig*: int32
-    shaderClockMhz*, reserved: cfloat
+    shaderClockMhz*: cfloat
+    gatherPath*: int32                    ## RTOW_GATHER_*: how rtow_render_multi brought the rows home
 
 proc rtow_last_error*(): cstring {.importc, dynlib: rtowLib.}
 proc rtow_create*(device: cint, ctx: ptr RtowCtx): cint {.importc, dynlib: rtowLib.}
 proc rtow_destroy*(ctx: RtowCtx): cint {.importc, dynlib: rtowLib.}
 proc rtow_set_scene_f64*(ctx: RtowCtx, n: cint, cx, cy, cz, radius: ptr cdouble, kind: ptr uint8,
                          albedoRgb, fuzz, ir: ptr cdouble): cint {.importc, dynlib: rtowLib.}
+proc rtow_set_hittables*(ctx: RtowCtx, n: cint, hittableKind: ptr uint8, cx, cy, cz, radius: ptr cdouble,
+                         materialKind: ptr uint8, albedoRgb, fuzz, ir: ptr cdouble): cint {.importc, dynlib: rtowLib.}
+proc rtow_multi_plan*(w, h, nCtx, tileRows: cint, ctxOfRow, indexInCtx, rowsPerCtx: ptr int32,
+                      slotBytes: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_set_camera_f64*(ctx: RtowCtx, cam: ptr RtowCameraF64): cint {.importc, dynlib: rtowLib.}
 proc rtow_render*(ctx: RtowCtx, w, h, spp, maxDepth: cint, seed: uint64, rows: ptr int32, nRows: cint,
                   rgbOut: ptr uint8, accumOut: ptr uint64, hitIdOut: ptr int32): cint {.importc, dynlib: rtowLib.}

@@ -56,6 +56,19 @@ typedef enum {
 /* MaterialKind, hitrecord.nim:16-17 */
 enum { RTOW_LAMBERTIAN = 0, RTOW_METAL = 1, RTOW_DIELECTRIC = 2 };
 
+/* HittableKind, hittables.nim:4-5: what an entry of the list is.  The reference's variant has the single
+ * member htSphere; the value travels through the ABI so that a list with another member is refused by name
+ * instead of being read as spheres. */
+enum { RTOW_HT_SPHERE = 0 };
+
+/* How rtow_render_multi brought the rows of its last frame to the host (rtow_stats.gather_path). */
+enum {
+  RTOW_GATHER_NONE = 0,            /* the context has not taken part in rtow_render_multi */
+  RTOW_GATHER_HOST = 1,            /* every context's rows copied to the host in turn */
+  RTOW_GATHER_RCCL = 2,            /* device to device over RCCL onto the first context's GPU, one copy to the host */
+  RTOW_GATHER_HOST_AFTER_RCCL = 3  /* RCCL was asked for but could not be used or failed: rows copied to the host in turn */
+};
+
 /* The eight private fields of Camera (camera.nim:4-10), rounded to binary32 by the host after
  * initCamera (camera.nim:12-31) has computed them in binary64. */
 typedef struct {
@@ -89,7 +102,7 @@ typedef struct {
   int32_t n_big;          /* spheres routed through the binary64 test */
   float shader_clock_mhz; /* clock the GPU ran at during that kernel: shader-clock ticks per tick of the
                              constant 100 MHz counter, read by the kernel's first wave as it starts and retires */
-  float reserved_;
+  int32_t gather_path;    /* RTOW_GATHER_*: set on every context of the last rtow_render_multi call */
 } rtow_stats;
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -128,6 +141,15 @@ int rtow_set_scene_f64(rtow_ctx* ctx, int n, const double* center_x, const doubl
                        const double* center_z, const double* radius, const uint8_t* kind,
                        const double* albedo_rgb, const double* fuzz, const double* ir);
 
+/* The same list as the reference holds it: an array of Hittable variants (hittables.nim:4-13), entry i being
+ * Hittable(kind: hittable_kind[i], hSphere: the i-th sphere of the arrays, which are those of rtow_set_scene_f64).
+ * hit*(h: Hittable, ...) (hittables.nim:75-77) dispatches on the kind and has one branch, htSphere; so does this
+ * call: RTOW_HT_SPHERE is the only kind it accepts, any other value is RTOW_ERR_INVALID with the index and the
+ * value in the message, and nothing is uploaded.  hittable_kind == NULL means every entry is a sphere. */
+int rtow_set_hittables(rtow_ctx* ctx, int n, const uint8_t* hittable_kind, const double* center_x,
+                       const double* center_y, const double* center_z, const double* radius,
+                       const uint8_t* material_kind, const double* albedo_rgb, const double* fuzz, const double* ir);
+
 /* Upload the camera (camera.nim:4-10): binary32 fields (widened exactly) or the binary64 ones. */
 int rtow_set_camera(rtow_ctx* ctx, const rtow_camera* cam);
 int rtow_set_camera_f64(rtow_ctx* ctx, const rtow_camera_f64* cam);
@@ -164,21 +186,25 @@ int rtow_sync(rtow_ctx* ctx);
 int rtow_render_pass(rtow_ctx* ctx, int w, int h, int first_sample, int n_samples, int max_depth,
                      uint64_t seed, const int32_t* rows, int n_rows, void* rgb_dev);
 
-/* rtow_render_async for callers that may not allocate: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc between set-up and tear-down.  It has no counterpart in
- * the reference (which has no device memory to manage).  The radiance sums and the work counters
- * live in a fixed array inside the library's code object instead of buffers from hipMalloc, and the
- * call makes no hipMalloc / hipFree or other allocating call; scene and camera must have been
- * uploaded before (rtow_set_scene allocates).  Differences from rtow_render_async:
+/* rtow_render_async for callers that may not allocate between set-up and tear-down: tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference (which has no device memory to
+ * manage).  The radiance sums and the work counters live in a fixed array inside the library's code object
+ * instead of buffers from hipMalloc, and the call makes no hipMalloc / hipFree or other allocating call;
+ * scene and camera must have been uploaded before (rtow_set_scene allocates).  It is NOT safe under HIP
+ * graph capture: like every render call it waits for the context's previous frame and records timing events.
+ * Differences from rtow_render_async:
  *   - rows_dev is a DEVICE pointer to n_rows row indices in [0, h) (or NULL with n_rows == h); the
  *     values are the caller's responsibility, the library cannot inspect them without a copy;
  *   - rgb_dev (device, n_rows*w*3 bytes) must not be NULL;
- *   - n_rows * w may not exceed 1 048 576 pixels (RTOW_ERR_INVALID beyond; 1200 x 800 fits);
+ *   - n_rows * w may not exceed 1 048 576 pixels (RTOW_ERR_INVALID beyond; 1200 x 800 fits), and
+ *     1 <= spp <= 4 194 304 as for rtow_render;
  *   - the image cannot be continued by rtow_render_pass or fetched with rtow_read_image /
  *     rtow_format_ppm: nothing of it stays in the context.
- * The array (25 MB) exists once per GPU and is shared by every context on that GPU: two such
- * renders that overlap in time on one GPU race on it and both images are garbage - order them
- * (one stream, or events).  The pixels equal rtow_render_async's bit for bit. */
+ * The array (25 MB) exists once per GPU and is shared by every context on that GPU, so one context at a time
+ * may have such a frame in flight there: the call takes the array for its context and gives it back when that
+ * context is next synchronised (rtow_sync, or any call that waits for the frame) or destroyed; a call on
+ * another context of the same GPU in between returns RTOW_ERR_STATE and renders nothing.  Calls on one context
+ * follow each other on its stream.  The pixels equal rtow_render_async's bit for bit. */
 int rtow_render_noalloc(rtow_ctx* ctx, int w, int h, int spp, int max_depth, uint64_t seed,
                         const int32_t* rows_dev, int n_rows, void* rgb_dev);
 
@@ -232,18 +258,32 @@ int rtow_scatter_rays(rtow_ctx* ctx, int n, const double* directions, const doub
 /* One frame on several contexts at once - normally one context per GPU of this process, each
  * holding the same scene and camera.  The rows of the image - the outer j loop of render
  * (raytracer.nim:36) - are dealt to the contexts in interleaved tiles of tile_rows rows (tile t goes
- * to context t mod n_ctx), every context renders its rows as rtow_render_async does, and the 8-bit
- * rows are copied into rgb_out (host, h*w*3 bytes, top row first).  The image is byte-identical to
- * what rtow_render produces on one context.  When the contexts sit on pairwise different GPUs the rows
- * are gathered device to device over RCCL (xGMI) onto the first context's GPU - all sends and receives
- * enqueued before anything is waited for - and reach the host in one copy; librccl.so is opened at
- * that moment (the copy already in the process, else the system's) and, if it cannot be, every
- * context's rows are copied to the host in turn, as they are for contexts that share a GPU.  ray_segments_out (may be NULL) receives the total
- * number of world.hit queries.  Each context's rtow_get_stats then describes its own share.
+ * to context t mod n_ctx; rtow_multi_plan below is that dealing), every context renders its rows as
+ * rtow_render_async does, and the 8-bit rows are copied into rgb_out (host, h*w*3 bytes, top row first).
+ * The image is byte-identical to what rtow_render produces on one context.  By default every context's rows
+ * are copied to the host in turn.  With RTOW_MULTI_GATHER=rccl in the environment and the contexts on
+ * pairwise different GPUs the rows are gathered device to device over RCCL (xGMI) onto the first context's
+ * GPU - librccl.so is opened and the communicators are built BEFORE the frame is enqueued, all sends and
+ * receives are enqueued before anything is waited for - and reach the host in one copy; if RCCL cannot be
+ * loaded or set up, or the exchange fails, the rows are copied to the host in turn after all
+ * (rtow_stats.gather_path says which way a frame went).  The RCCL branch with two or more GPUs has not run
+ * on hardware yet (the build's machines have one GPU), which is why it is opt-in.  ray_segments_out (may be
+ * NULL) receives the total number of world.hit queries.  Each context's rtow_get_stats then describes its own
+ * share.
  * Hosts that run one PROCESS per GPU use rtow_render_async with their own row list instead and
  * exchange the rows themselves (the Python host does so with torch.distributed over RCCL). */
 int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, int max_depth,
                       uint64_t seed, int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out);
+
+/* The dealing of rows behind rtow_render_multi, as plain arithmetic (no device is touched): image row y
+ * (0 = top) belongs to context (y / tile_rows) mod n_ctx and is that context's index_in_ctx[y]-th row; context k
+ * renders rows_per_ctx[k] rows (0 when there are fewer tiles than contexts).  *slot_bytes is what each
+ * context's rows occupy in the gather buffer of the RCCL path: the largest share, 3*w bytes per row, rounded
+ * up to a multiple of 256; row y of the image is read from byte  slot * ctx_of_row[y] + 3*w * index_in_ctx[y].
+ * ctx_of_row and index_in_ctx have h entries, rows_per_ctx n_ctx; any output may be NULL.  Hosts that run one
+ * process per GPU and exchange the rows themselves deal the rows the same way. */
+int rtow_multi_plan(int w, int h, int n_ctx, int tile_rows, int32_t* ctx_of_row, int32_t* index_in_ctx,
+                    int32_t* rows_per_ctx, uint64_t* slot_bytes);
 
 /* The PPM file of the most recent render on this context, as the reference writes it: the header
  * "P3\n{w} {rows}\n255\n" (raytracer.nim:35) followed by one "r g b\n" line per pixel

@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTOW_LIB_PATH") or os.path.join(_HERE, "lib", "librtow_hip.so")
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
+HT_SPHERE = 0                                   # HittableKind (hittables.nim:4-5)
+GATHER_NONE, GATHER_HOST, GATHER_RCCL, GATHER_HOST_AFTER_RCCL = 0, 1, 2, 3   # rtow_stats.gather_path
 
 
 class RtowError(RuntimeError):
@@ -39,13 +41,13 @@ class CameraStruct64(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ray_segments", C.c_uint64), ("paths", C.c_uint64), ("trace_ms", C.c_float),
                 ("total_ms", C.c_float), ("n_spheres", C.c_int32), ("n_big", C.c_int32),
-                ("shader_clock_mhz", C.c_float), ("reserved_", C.c_float)]
+                ("shader_clock_mhz", C.c_float), ("gather_path", C.c_int32)]
 
 
 # every symbol include/rtow.h declares
 SYMBOLS = ["rtow_last_error", "rtow_version", "rtow_device_count", "rtow_create", "rtow_destroy",
-           "rtow_set_scene", "rtow_set_scene_f64", "rtow_set_camera", "rtow_set_camera_f64", "rtow_render", "rtow_render_async", "rtow_sync",
-           "rtow_render_multi", "rtow_trace_rays", "rtow_get_rays", "rtow_scatter_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
+           "rtow_set_scene", "rtow_set_scene_f64", "rtow_set_hittables", "rtow_set_camera", "rtow_set_camera_f64", "rtow_render", "rtow_render_async", "rtow_sync",
+           "rtow_render_multi", "rtow_multi_plan", "rtow_trace_rays", "rtow_get_rays", "rtow_scatter_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
 
 _lib = None
 
@@ -113,6 +115,8 @@ def load(path, strict=True):
     L.rtow_destroy.argtypes = [vp]
     L.rtow_set_scene.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtow_set_scene_f64.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rtow_set_hittables.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rtow_multi_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(C.c_uint64)]
     L.rtow_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     L.rtow_set_camera_f64.argtypes = [vp, C.POINTER(CameraStruct64)]
     L.rtow_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp, vp, vp]

@@ -73,6 +73,10 @@ namespace {
 // Device address of `scratch` on each GPU (the array's name is only a host-side handle): looked up
 // once per device by rtow_create with that device current.  The same value whichever thread stores it.
 std::atomic<unsigned char*> g_scratch_ptr[kMaxDevices];
+// The context whose rtow_render_noalloc frame currently owns this GPU's copy of the array (nullptr: free).  Taken by
+// the call, given back when that context is synchronised (rtow_sync and every call that waits for the frame) or
+// destroyed: a second context that asks for the array in between is refused instead of racing on it.
+std::atomic<rtow_ctx*> g_scratch_owner[kMaxDevices];
 }  // namespace
 
 // RCCL, bound at run time: the library is only needed by rtow_render_multi on two or more GPUs, so it is
@@ -172,6 +176,7 @@ struct rtow_ctx {
 
   // last render
   bool pending = false;
+  bool holds_scratch = false;                 // the frame in flight keeps its sums in this GPU's no-allocation work memory
   int last_w = 0, last_h = 0, last_spp = 0, last_rows = 0;
   int samples_done = 0;                       // samples per pixel in the accumulators
   uint64_t last_seed = 0;
@@ -179,6 +184,14 @@ struct rtow_ctx {
   bool last_row_list_valid = false;
   rtow_stats stats = {};
 };
+
+// Gives this GPU's no-allocation work memory back once the frame that used it has been waited for.
+static void release_scratch(rtow_ctx* c) {
+  if (!c->holds_scratch) return;
+  c->holds_scratch = false;
+  rtow_ctx* expected = c;
+  if (c->device < kMaxDevices) g_scratch_owner[c->device].compare_exchange_strong(expected, nullptr, std::memory_order_acq_rel);
+}
 
 // Device-to-host copy of a large buffer into ordinary (pageable) caller memory: the runtime stages
 // such copies through a small internal buffer at a few GB/s; two pinned 8 MB buffers used in turn -
@@ -258,6 +271,7 @@ int rtow_destroy(rtow_ctx* c) {
   if (!c) return RTOW_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  release_scratch(c);
   c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom_slab.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release(); c->ray_in.release(); c->ray_out.release(); c->gather.release();
@@ -305,6 +319,18 @@ int rtow_set_scene_f64(rtow_ctx* c, int n, const double* cx, const double* cy, c
                        const double* radius, const uint8_t* kind, const double* albedo, const double* fuzz,
                        const double* ir) {
   return set_scene_guarded<double>(c, n, cx, cy, cz, radius, kind, albedo, fuzz, ir);
+}
+
+int rtow_set_hittables(rtow_ctx* c, int n, const uint8_t* hittable_kind, const double* cx, const double* cy,
+                       const double* cz, const double* radius, const uint8_t* material_kind, const double* albedo,
+                       const double* fuzz, const double* ir) {
+  // hit*(h: Hittable) (hittables.nim:75-77) is a case over HittableKind with the one branch htSphere
+  if (hittable_kind)
+    for (int j = 0; j < n; ++j)
+      if (hittable_kind[j] != RTOW_HT_SPHERE)
+        return fail(RTOW_ERR_INVALID, "rtow_set_hittables: entry %d has HittableKind %d; the only kind is htSphere (%d)", j,
+                    (int)hittable_kind[j], (int)RTOW_HT_SPHERE);
+  return set_scene_guarded<double>(c, n, cx, cy, cz, radius, material_kind, albedo, fuzz, ir);
 }
 
 }  // extern "C"
@@ -564,7 +590,7 @@ static int enqueue_render(rtow_ctx* c, int w, int h, int spp, int max_depth, uin
   if (n_pixels >= 0x7fffffffull / 3) return fail(RTOW_ERR_INVALID, "render: %llu pixels in one call", (unsigned long long)n_pixels);
 
   HIP_TRY(hipSetDevice(c->device));
-  if (c->pending) HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->pending) { HIP_TRY(hipStreamSynchronize(c->stream)); release_scratch(c); }
 
   try {
     if (first_sample == 0) {
@@ -608,12 +634,14 @@ int rtow_sync(rtow_ctx* c) {
   if (!c) return fail(RTOW_ERR_INVALID, "rtow_sync: ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  release_scratch(c);
   if (c->pending) {
     c->pending = false;
     c->stats.ray_segments = c->host_counters[0];
     c->stats.paths = (uint64_t)c->last_rows * (uint64_t)c->last_w * (uint64_t)c->last_spp;
     c->stats.n_spheres = c->n_spheres;
     c->stats.n_big = c->n_big;
+    c->stats.gather_path = RTOW_GATHER_NONE;   // rtow_render_multi sets it once its rows are home
     {
       const uint64_t ticks = c->host_counters[4] - c->host_counters[2], ref = c->host_counters[5] - c->host_counters[3];
       c->stats.shader_clock_mhz = ref > 0 && c->host_counters[5] > c->host_counters[3] ? (float)((double)ticks / (double)ref * 100.0) : 0.0f;
@@ -643,6 +671,8 @@ int rtow_render_noalloc(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   if (!rgb_dev) return fail(RTOW_ERR_INVALID, "rtow_render_noalloc: rgb_dev is NULL (the image has nowhere to go)");
   if (w < 2 || h < 2) return fail(RTOW_ERR_INVALID, "render: image %dx%d (width and height must be >= 2)", w, h);
   if (spp < 1 || max_depth < 1) return fail(RTOW_ERR_INVALID, "render: spp = %d, max_depth = %d", spp, max_depth);
+  if (spp > rtow::kMaxSamplesPerPixel)
+    return fail(RTOW_ERR_INVALID, "render: spp = %d (a pixel's 64-bit sums hold at most %d samples)", spp, rtow::kMaxSamplesPerPixel);
   if (n_rows < 0 || n_rows > h) return fail(RTOW_ERR_INVALID, "render: n_rows = %d of %d", n_rows, h);
   if (!rows_dev && n_rows != h) return fail(RTOW_ERR_INVALID, "render: rows_dev == NULL needs n_rows == h");
   const uint64_t n_pixels = (uint64_t)n_rows * (uint64_t)w;
@@ -650,8 +680,17 @@ int rtow_render_noalloc(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
     return fail(RTOW_ERR_INVALID, "rtow_render_noalloc: %llu pixels in one call, the fixed work memory holds %u "
                                   "(use rtow_render_async, or render the frame in row bands)",
                 (unsigned long long)n_pixels, kNoAllocMaxPixels);
+  if (c->device >= kMaxDevices) return fail(RTOW_ERR_STATE, "rtow_render_noalloc: device %d", c->device);
   HIP_TRY(hipSetDevice(c->device));
   if (c->pending) HIP_TRY(hipStreamSynchronize(c->stream));   // this context's events and counters are still in use
+  {
+    // one context at a time owns this GPU's work memory; it keeps it until it has been synchronised
+    rtow_ctx* owner = nullptr;
+    if (!g_scratch_owner[c->device].compare_exchange_strong(owner, c, std::memory_order_acq_rel) && owner != c)
+      return fail(RTOW_ERR_STATE, "rtow_render_noalloc: the work memory of device %d is in use by a frame of another "
+                                  "context; rtow_sync that context first", c->device);
+    c->holds_scratch = true;
+  }
   FrameTargets t;
   t.rows_dev = rows_dev;
   t.counters = c->scratch_dev;
@@ -663,7 +702,9 @@ int rtow_render_noalloc(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   c->last_row_list_valid = false;
   c->image_in_workspace = false;
   c->sums_in_workspace = false;
-  return launch_frame(c, w, h, spp, max_depth, seed, 0, n_rows, t);
+  const int rc = launch_frame(c, w, h, spp, max_depth, seed, 0, n_rows, t);
+  if (rc != RTOW_OK) { (void)hipStreamSynchronize(c->stream); release_scratch(c); }
+  return rc;
 }
 
 int rtow_read_image(rtow_ctx* c, uint8_t* rgb_out, uint64_t* accum_out) {
@@ -714,35 +755,58 @@ int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, i
 
 }  // extern "C"
 
+// The dealing of rows behind rtow_render_multi (also exported as rtow_multi_plan): row y belongs to context
+// (y / tile_rows) mod n_ctx - sky rows cost one segment per path and ground rows several, so contiguous bands
+// would be unbalanced - and a context's rows keep their image order.
+struct MultiPlan {
+  std::vector<std::vector<int32_t>> rows;   // per context: its image rows, ascending
+  size_t row_bytes = 0;                     // 3 * w
+  size_t slot = 0;                          // bytes per context in the gather buffer: the largest share, rounded up to 256
+};
+
+static MultiPlan multi_plan(int w, int h, int n_ctx, int tile_rows) {
+  MultiPlan p;
+  p.rows.resize((size_t)n_ctx);
+  for (int y = 0; y < h; ++y) p.rows[(size_t)((y / tile_rows) % n_ctx)].push_back(y);
+  p.row_bytes = 3 * (size_t)w;
+  for (const auto& r : p.rows) p.slot = std::max(p.slot, p.row_bytes * r.size());
+  p.slot = (p.slot + 255) & ~(size_t)255;
+  return p;
+}
+
+// The RCCL clique of an ordered device list: looked up, or created on first use and kept for the life of the
+// process.  Called BEFORE a frame is enqueued - communicator construction launches kernels of its own and must
+// not meet GPUs that a persistent trace grid occupies.  nullptr (with the reason in `why`) when RCCL cannot be used.
+// The caller holds g_rccl_mutex.
+static std::vector<ncclComm_t>* rccl_clique(const std::vector<int>& devs, std::string& why) {
+  if (const char* missing = rccl_load()) { why = missing; return nullptr; }
+  std::vector<ncclComm_t>& comms = g_rccl.comms[devs];
+  if (comms.empty()) {
+    comms.resize(devs.size());
+    const ncclResult_t e = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+    if (e != ncclSuccess) {
+      why = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(e);
+      g_rccl.comms.erase(devs);
+      return nullptr;
+    }
+  }
+  return &comms;
+}
+
 // The framebuffer gather of rtow_render_multi over RCCL.  Every context k > 0 sends its rows (they are still being
 // rendered: the send is ordered behind the render on that context's stream) to the first context's GPU, which
 // receives them side by side; all sends and receives are enqueued in one group before anything is waited for.  Then
-// one copy into pinned host memory and the rows are dealt into the caller's image.
-// Returns RTOW_ERR_STATE (with every context drained) when RCCL cannot be used at all.
-static int gather_rccl(rtow_ctx* const* ctxs, int n_ctx, int w, const std::vector<std::vector<int32_t>>& rows, uint8_t* rgb_out,
-                       uint64_t* ray_segments_out) {
-  std::lock_guard<std::mutex> lock(g_rccl_mutex);
-  auto drain = [&]() { for (int k = 0; k < n_ctx; ++k) (void)rtow_sync(ctxs[k]); };
-  if (const char* why = rccl_load()) { drain(); return fail(RTOW_ERR_STATE, "rtow_render_multi: %s", why); }
-  std::vector<int> devs((size_t)n_ctx);
-  for (int k = 0; k < n_ctx; ++k) devs[(size_t)k] = ctxs[k]->device;
-  std::vector<ncclComm_t>& comms = g_rccl.comms[devs];
-  if (comms.empty()) {
-    comms.resize((size_t)n_ctx);
-    const ncclResult_t e = g_rccl.CommInitAll(comms.data(), n_ctx, devs.data());
-    if (e != ncclSuccess) {
-      g_rccl.comms.erase(devs);
-      drain();
-      return fail(RTOW_ERR_STATE, "rtow_render_multi: ncclCommInitAll over %d devices: %s", n_ctx, g_rccl.GetErrorString(e));
-    }
-  }
-  const size_t row_bytes = 3 * (size_t)w;
-  size_t slot = 0;   // bytes per context in the receive buffer
-  for (int k = 0; k < n_ctx; ++k) slot = std::max(slot, row_bytes * rows[(size_t)k].size());
-  slot = (slot + 255) & ~(size_t)255;
+// one copy into pinned host memory and the rows are dealt into the caller's image.  Every context is drained before
+// this returns, whatever happens; a failure leaves rgb_out untouched, so the caller can still copy the rows - which
+// are complete in every context's own image buffer - through the host.
+static int gather_rccl(rtow_ctx* const* ctxs, int n_ctx, const MultiPlan& plan, std::vector<ncclComm_t>& comms,
+                       uint8_t* rgb_out, uint64_t* ray_segments_out) {
+  const size_t row_bytes = plan.row_bytes, slot = plan.slot;
   rtow_ctx* c0 = ctxs[0];
   int rc = RTOW_OK;
   auto body = [&]() -> int {
+    // tests only: the exchange "fails" before anything is sent, so that the way back through the host copies runs
+    if (getenv("RTOW_RCCL_INJECT_FAILURE")) return fail(RTOW_ERR_DEVICE, "rtow_render_multi: RCCL failure injected by the environment");
     HIP_TRY(hipSetDevice(c0->device));
     HIP_TRY(c0->gather.reserve(slot * (size_t)n_ctx ? slot * (size_t)n_ctx : 256));
     if (c0->gather_host_cap < slot * (size_t)n_ctx) {
@@ -752,7 +816,7 @@ static int gather_rccl(rtow_ctx* const* ctxs, int n_ctx, int w, const std::vecto
     }
     ncclResult_t e = g_rccl.GroupStart();
     for (int k = 1; k < n_ctx && e == ncclSuccess; ++k) {
-      const size_t bytes = row_bytes * rows[(size_t)k].size();
+      const size_t bytes = row_bytes * plan.rows[(size_t)k].size();
       if (bytes == 0) continue;
       e = g_rccl.Send(ctxs[k]->rgb.p, bytes, ncclUint8, 0, comms[(size_t)k], ctxs[k]->stream);
       if (e == ncclSuccess) e = g_rccl.Recv((char*)c0->gather.p + slot * (size_t)k, bytes, ncclUint8, k, comms[0], c0->stream);
@@ -762,7 +826,7 @@ static int gather_rccl(rtow_ctx* const* ctxs, int n_ctx, int w, const std::vecto
     if (e != ncclSuccess) return fail(RTOW_ERR_DEVICE, "rtow_render_multi: RCCL send/receive: %s", g_rccl.GetErrorString(e));
     // the first context's own rows join the others on its own stream, behind its render and the receives
     HIP_TRY(hipSetDevice(c0->device));
-    const size_t own = row_bytes * rows[0].size();
+    const size_t own = row_bytes * plan.rows[0].size();
     if (own) HIP_TRY(hipMemcpyAsync(c0->gather.p, c0->rgb.p, own, hipMemcpyDeviceToDevice, c0->stream));
     HIP_TRY(hipMemcpyAsync(c0->gather_host, c0->gather.p, slot * (size_t)n_ctx, hipMemcpyDeviceToHost, c0->stream));
     return RTOW_OK;
@@ -776,7 +840,7 @@ static int gather_rccl(rtow_ctx* const* ctxs, int n_ctx, int w, const std::vecto
   }
   if (rc != RTOW_OK) return rc;
   for (int k = 0; k < n_ctx; ++k) {
-    const std::vector<int32_t>& r = rows[(size_t)k];
+    const std::vector<int32_t>& r = plan.rows[(size_t)k];
     for (size_t i = 0; i < r.size(); ++i)
       memcpy(rgb_out + row_bytes * (size_t)r[i], c0->gather_host + slot * (size_t)k + row_bytes * i, row_bytes);
   }
@@ -788,19 +852,36 @@ static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int
                              int tile_rows, uint8_t* rgb_out, uint64_t* ray_segments_out) {
   if (!ctxs || n_ctx < 1) return fail(RTOW_ERR_INVALID, "rtow_render_multi: no contexts");
   if (tile_rows < 1) return fail(RTOW_ERR_INVALID, "rtow_render_multi: tile_rows = %d", tile_rows);
-  if (h < 2) return fail(RTOW_ERR_INVALID, "render: image %dx%d (width and height must be >= 2)", w, h);
+  if (w < 2 || h < 2) return fail(RTOW_ERR_INVALID, "render: image %dx%d (width and height must be >= 2)", w, h);
   for (int k = 0; k < n_ctx; ++k) {
     if (!ctxs[k]) return fail(RTOW_ERR_INVALID, "rtow_render_multi: ctxs[%d] is NULL", k);
     for (int j = 0; j < k; ++j)
       if (ctxs[j] == ctxs[k]) return fail(RTOW_ERR_INVALID, "rtow_render_multi: ctxs[%d] and ctxs[%d] are the same context", j, k);
   }
-  // rows of context k: tiles k, k + n_ctx, k + 2 n_ctx, ... (sky rows cost one segment per path and
-  // ground rows several, so contiguous bands would be unbalanced)
-  std::vector<std::vector<int32_t>> rows((size_t)n_ctx);
-  for (int y = 0; y < h; ++y) rows[(size_t)((y / tile_rows) % n_ctx)].push_back(y);
+  const MultiPlan plan = multi_plan(w, h, n_ctx, tile_rows);
+  // How the rows come home.  Default: every context's rows are copied to the host in turn.  RTOW_MULTI_GATHER=rccl asks for
+  // the device-to-device gather over RCCL (xGMI) onto the first context's GPU; it needs pairwise different GPUs (a clique
+  // of one context is allowed: nothing is sent).  The communicators are looked up or built HERE, before any context
+  // has work enqueued.  Whatever goes wrong on that way, the host copies still deliver the frame.
+  bool all_different = true;
+  for (int k = 0; k < n_ctx; ++k)
+    for (int j = 0; j < k; ++j) all_different = all_different && ctxs[j]->device != ctxs[k]->device;
+  const char* mode = getenv("RTOW_MULTI_GATHER");
+  const bool want_rccl = mode && !strcmp(mode, "rccl") && all_different && rgb_out;
+  int path = RTOW_GATHER_HOST;
+  std::unique_lock<std::mutex> rccl_lock(g_rccl_mutex, std::defer_lock);
+  std::vector<ncclComm_t>* comms = nullptr;
+  if (want_rccl) {
+    rccl_lock.lock();   // collectives on one clique are serialised; held until the gather has been waited for
+    std::vector<int> devs((size_t)n_ctx);
+    for (int k = 0; k < n_ctx; ++k) devs[(size_t)k] = ctxs[k]->device;
+    std::string why;
+    comms = rccl_clique(devs, why);
+    if (!comms) { rccl_lock.unlock(); path = RTOW_GATHER_HOST_AFTER_RCCL; }
+  }
   for (int k = 0; k < n_ctx; ++k) {
     static const int32_t no_rows[1] = {0};  // a context left without rows still takes part (and reports zero segments)
-    const std::vector<int32_t>& r = rows[(size_t)k];
+    const std::vector<int32_t>& r = plan.rows[(size_t)k];
     const int rc = enqueue_render(ctxs[k], w, h, spp, max_depth, seed, r.empty() ? no_rows : r.data(), (int)r.size(),
                                   nullptr, false);
     if (rc != RTOW_OK) {
@@ -808,44 +889,33 @@ static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int
       return rc;
     }
   }
-  // The contexts sit on pairwise different GPUs (two or more): the 8-bit rows travel device to device over RCCL
-  // (xGMI) to the first context's GPU and reach the host in one copy.  Otherwise (several contexts on one GPU,
-  // or a single context) every context's rows are copied to the host in turn.  RTOW_MULTI_GATHER=host forces the
-  // second form, =rccl the first (also for a single context: the clique then has one rank and nothing is sent).
-  bool distinct = n_ctx >= 2;
-  for (int k = 0; k < n_ctx && distinct; ++k)
-    for (int j = 0; j < k; ++j)
-      if (ctxs[j]->device == ctxs[k]->device) { distinct = false; break; }
-  bool use_rccl = distinct;
-  if (const char* e = getenv("RTOW_MULTI_GATHER")) {
-    if (!strcmp(e, "host")) use_rccl = false;
-    else if (!strcmp(e, "rccl")) {
-      bool all_different = true;
-      for (int k = 0; k < n_ctx; ++k)
-        for (int j = 0; j < k; ++j) all_different = all_different && ctxs[j]->device != ctxs[k]->device;
-      use_rccl = all_different;
+  if (comms) {
+    const int rc = gather_rccl(ctxs, n_ctx, plan, *comms, rgb_out, ray_segments_out);
+    rccl_lock.unlock();
+    if (rc == RTOW_OK) {
+      for (int k = 0; k < n_ctx; ++k) ctxs[k]->stats.gather_path = RTOW_GATHER_RCCL;
+      return RTOW_OK;
     }
-  }
-  if (use_rccl && rgb_out) {
-    const int rc = gather_rccl(ctxs, n_ctx, w, rows, rgb_out, ray_segments_out);
-    if (rc != RTOW_ERR_STATE) return rc;   // RTOW_ERR_STATE: RCCL is not available - the host path below still works
+    path = RTOW_GATHER_HOST_AFTER_RCCL;   // every context has been drained; its rows are intact in its own image buffer
   }
   uint64_t segments = 0;
   int first_error = RTOW_OK;
   std::vector<uint8_t> staging;
-  const size_t row_bytes = 3 * (size_t)w;
+  const size_t row_bytes = plan.row_bytes;
   for (int k = 0; k < n_ctx; ++k) {
     rtow_ctx* c = ctxs[k];
     int rc = rtow_sync(c);   // every context is drained even after a failure
-    const std::vector<int32_t>& r = rows[(size_t)k];
+    const std::vector<int32_t>& r = plan.rows[(size_t)k];
     if (rc == RTOW_OK && rgb_out && !r.empty()) {
       staging.resize(row_bytes * r.size());
-      const hipError_t e = hipMemcpy(staging.data(), c->rgb.p, staging.size(), hipMemcpyDeviceToHost);
+      hipError_t e = hipSetDevice(c->device);
+      if (e == hipSuccess) e = hipMemcpy(staging.data(), c->rgb.p, staging.size(), hipMemcpyDeviceToHost);
       if (e != hipSuccess) rc = fail(RTOW_ERR_DEVICE, "rtow_render_multi: %s", hipGetErrorString(e));
       else
         for (size_t i = 0; i < r.size(); ++i)
           memcpy(rgb_out + row_bytes * (size_t)r[i], staging.data() + row_bytes * i, row_bytes);
     }
+    c->stats.gather_path = path;
     if (rc == RTOW_OK) segments += c->stats.ray_segments;
     else if (first_error == RTOW_OK) first_error = rc;
   }
@@ -853,6 +923,31 @@ static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int
   if (ray_segments_out) *ray_segments_out = segments;
   return RTOW_OK;
 }
+
+extern "C" {
+
+int rtow_multi_plan(int w, int h, int n_ctx, int tile_rows, int32_t* ctx_of_row, int32_t* index_in_ctx,
+                    int32_t* rows_per_ctx, uint64_t* slot_bytes) {
+  if (w < 1 || h < 0 || n_ctx < 1 || tile_rows < 1)
+    return fail(RTOW_ERR_INVALID, "rtow_multi_plan: w = %d, h = %d, n_ctx = %d, tile_rows = %d", w, h, n_ctx, tile_rows);
+  try {
+    const MultiPlan p = multi_plan(w, h, n_ctx, tile_rows);
+    for (int k = 0; k < n_ctx; ++k) {
+      const std::vector<int32_t>& r = p.rows[(size_t)k];
+      if (rows_per_ctx) rows_per_ctx[k] = (int32_t)r.size();
+      for (size_t i = 0; i < r.size(); ++i) {
+        if (ctx_of_row) ctx_of_row[r[i]] = k;
+        if (index_in_ctx) index_in_ctx[r[i]] = (int32_t)i;
+      }
+    }
+    if (slot_bytes) *slot_bytes = p.slot;
+  } catch (const std::bad_alloc&) {
+    return fail(RTOW_ERR_NOMEM, "rtow_multi_plan: out of host memory");
+  }
+  return RTOW_OK;
+}
+
+}  // extern "C"
 
 extern "C" {
 

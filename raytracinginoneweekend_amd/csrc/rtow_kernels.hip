@@ -1333,7 +1333,19 @@ __global__ void __launch_bounds__(256) rtow_rays_kernel(const RayParams P) {
   const double a = dx * dx + dy * dy + dz * dz;
   // ---- hit(world, r, t_min, t_max, rec) in binary64, list order, shrinking t_max
   f3 o = {(float)ox, (float)oy, (float)oz};
-  f3 d = {(float)dx, (float)dy, (float)dz};
+  // The screen and the shading use the binary32 unit direction.  The caller's direction is binary64 and not
+  // normalised: one whose length leaves binary32's range (below about 1e-19 or above 1e19, where |d|^2 under- or
+  // overflows) is first scaled by a power of two - exact in binary64, and the unit direction of a ray does not
+  // change by it, bit for bit - so that its largest component lands in [1, 2).
+  double sdx = dx, sdy = dy, sdz = dz;
+  {
+    const double dm = fmax(fabs(dx), fmax(fabs(dy), fabs(dz)));
+    if ((dm < 0x1p-60 || dm > 0x1p60) && dm > 0.0 && dm < INFINITY) {
+      const int e = -ilogb(dm);
+      sdx = ldexp(dx, e); sdy = ldexp(dy, e); sdz = ldexp(dz, e);
+    }
+  }
+  f3 d = {(float)sdx, (float)sdy, (float)sdz};
   f3 u;
   float tmin;
   segment_begin(d, u, tmin);

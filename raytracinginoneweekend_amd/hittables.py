@@ -12,7 +12,9 @@ htSphere = 0
 
 
 class Hittable:
-    """hittables.nim:4-8: a variant with a single member today."""
+    """hittables.nim:4-8: a variant with a single member today.  `kind` is kept as given: a value other than
+    htSphere travels to the library with the list and is refused there (rtow_set_hittables), as the reference's
+    `case h.kind` (hittables.nim:75-77) has no branch for it."""
 
     def __init__(self, kind=htSphere, hSphere=None):
         self.kind = kind
@@ -61,8 +63,10 @@ class HittablesList:
             "center_z": np.empty(n, np.float64), "radius": np.empty(n, np.float64),
             "kind": np.empty(n, np.uint8), "albedo": np.empty((n, 3), np.float64),
             "fuzz": np.empty(n, np.float64), "ir": np.empty(n, np.float64),
+            "hittable_kind": np.empty(n, np.uint8),    # Hittable.kind per entry (hittables.nim:6)
         }
         for j, h in enumerate(self._data):
+            out["hittable_kind"][j] = h.kind
             s = h.hSphere
             kind, albedo, fuzz, ir = s.mat.flat()
             out["center_x"][j], out["center_y"][j], out["center_z"][j] = s.center[0], s.center[1], s.center[2]
@@ -79,7 +83,18 @@ def initHittables(size=8):
 
 
 def hit(h, r, t_min, t_max, rec):
-    """hit*(h: var HittablesList, r: Ray, t_min, t_max: float, rec: var HitRecord): bool (hittables.nim:79-88);
-    the search over the list runs on the GPU (raytracer.hit)."""
+    """The reference's three overloads of hit*, told apart by the type of `h` as Nim's overload resolution does:
+      hit*(h: var HittablesList, r, t_min, t_max, rec)  hittables.nim:79-88  closest hit over the list
+      hit*(h: Hittable, r, t_min, t_max, rec)           hittables.nim:75-77  case h.kind of htSphere: h.hSphere.hit
+      hit*(s: Sphere, r, t_min, t_max, rec)             hitrecord.nim:55-79  one sphere
+    All three run on the GPU (raytracer.hit); the one-object forms are a query against a one-entry list."""
     from . import raytracer
+    if isinstance(h, Hittable):
+        if h.kind != htSphere:   # the reference's case statement has no other branch
+            raise ValueError(f"hit: Hittable of kind {h.kind}; the only HittableKind is htSphere ({htSphere})")
+        h = h.hSphere
+    if isinstance(h, Sphere):
+        one = HittablesList()
+        one.add(h)
+        return raytracer.hit(one, r, t_min, t_max, rec)
     return raytracer.hit(h, r, t_min, t_max, rec)

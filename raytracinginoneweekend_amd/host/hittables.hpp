@@ -8,7 +8,7 @@
 
 namespace rtowhost {
 
-enum HittableKind { htSphere };
+enum HittableKind { htSphere };   // hittables.nim:4-5: one member; the value travels to the library, which refuses any other
 struct Hittable { HittableKind kind = htSphere; Sphere hSphere; };  // hittables.nim:4-8
 
 class HittablesList {
@@ -24,13 +24,15 @@ class HittablesList {
 
   struct Flat {
     std::vector<double> cx, cy, cz, radius, albedo, fuzz, ir;   // Nim float = binary64
-    std::vector<uint8_t> kind;
+    std::vector<uint8_t> kind;           // MaterialKind of the sphere's material
+    std::vector<uint8_t> hittableKind;   // Hittable.kind (hittables.nim:6), for rtow_set_hittables
   };
   // list order is kept: index i here is insertion index i, which decides ties (hittables.nim:84-88)
   Flat flatten() const {
     Flat f;
     for (const Hittable& h : data_) {
       const Sphere& s = h.hSphere;
+      f.hittableKind.push_back((uint8_t)h.kind);
       f.cx.push_back(s.center[0]); f.cy.push_back(s.center[1]); f.cz.push_back(s.center[2]);
       f.radius.push_back(s.radius);
       f.kind.push_back((uint8_t)s.mat.kind);

@@ -2,6 +2,8 @@
 //   rtow_raytracer [--width W] [--ratio R] [--spp N] [--depth D] [--scene random|mix|redblue]
 //                  [--half-extent E] [--out file.ppm] [--device K | --devices K0,K1,...] [--dump-scene]
 //                  [--probe S T]   getRay(camera, S, T), then hit, rayColor and scatter of that ray: one line of numbers
+//                  [--probe-one J] with --probe: also hit(Sphere) and hit(Hittable) of list entry J alone (two more lines)
+//                  [--corrupt-kind J]  give list entry J a HittableKind the reference does not have (the upload must fail)
 // --devices spreads the frame over several GPUs (an index may repeat); the image does not change.
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +19,7 @@ int main(int argc, char** argv) {
   double ratio = 3.0 / 2.0;
   std::string out = "/tmp/test_small.ppm", scene = "random";
   bool dump = false, probe = false;
+  int probeOne = -1, corruptKind = -1;
   double probeS = 0.5, probeT = 0.5;
   std::vector<int> devices;
   for (int i = 1; i < argc; ++i) {
@@ -39,11 +42,14 @@ int main(int argc, char** argv) {
     }
     else if (a == "--dump-scene") dump = true;
     else if (a == "--probe") { probe = true; probeS = std::atof(val()); probeT = std::atof(val()); }
+    else if (a == "--probe-one") probeOne = std::atoi(val());
+    else if (a == "--corrupt-kind") corruptKind = std::atoi(val());
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
   try {
     const Image img{width, (int)(width / ratio)};
     HittablesList world = scene == "mix" ? mixOfSpheres() : scene == "redblue" ? sceneRedBlue() : randomScene(halfExtent);
+    if (corruptKind >= 0 && corruptKind < world.len()) world[corruptKind].kind = (HittableKind)1;
     if (dump) {  // one line per sphere, full precision: lets a test compare the scene with the oracle's
       for (const Hittable& h : world) {
         const Sphere& s = h.hSphere;
@@ -73,6 +79,15 @@ int main(int argc, char** argv) {
                   r.orig[0], r.orig[1], r.orig[2], r.dir[0], r.dir[1], r.dir[2], (int)h, rec.index, rec.t, rec.p[0], rec.p[1],
                   rec.p[2], rec.normal[0], rec.normal[1], rec.normal[2], (int)rec.frontFace, c[0], c[1], c[2],
                   (int)s, att[0], att[1], att[2], sc.dir[0], sc.dir[1], sc.dir[2]);
+      if (probeOne >= 0 && probeOne < world.len()) {   // the one-object overloads of hit, against list entry probeOne alone
+        for (int form = 0; form < 2; ++form) {
+          HitRecord one;
+          const bool h1 = form == 0 ? hit(world[probeOne].hSphere, dev, r, 0.001, INFINITY, one)
+                                    : hit(world[probeOne], dev, r, 0.001, INFINITY, one);
+          std::printf("%d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %d\n", (int)h1, one.t, one.p[0], one.p[1], one.p[2],
+                      one.normal[0], one.normal[1], one.normal[2], (int)one.frontFace);
+        }
+      }
       return 0;
     }
     if (!devices.empty()) {

@@ -29,6 +29,14 @@ inline void writePPM(const std::string& path, int w, int h, const std::vector<ui
   std::fclose(f);
 }
 
+// Upload a list as the reference holds it: Hittable.kind per entry beside the sphere arrays (the library has, like
+// hit*(h: Hittable) of hittables.nim:75-77, the one branch htSphere and refuses anything else).
+inline void upload(rtow_ctx* ctx, const HittablesList& world) {
+  const HittablesList::Flat s = world.flatten();
+  check(rtow_set_hittables(ctx, world.len(), s.hittableKind.data(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(),
+                           s.kind.data(), s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_hittables");
+}
+
 // render*(img, f, world, camera, samplesPerPixel, maxDepth)  (raytracer.nim:30-46)
 inline std::vector<uint8_t> render(const Image& img, const std::string& f, const HittablesList& world,
                                    const Camera& camera, int samplesPerPixel, int maxDepth,
@@ -37,9 +45,7 @@ inline std::vector<uint8_t> render(const Image& img, const std::string& f, const
   check(rtow_create(device, &ctx), "rtow_create");
   std::vector<uint8_t> rgb((size_t)img.width * (size_t)img.height * 3);
   try {
-    const HittablesList::Flat s = world.flatten();
-    check(rtow_set_scene_f64(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
-                         s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene_f64");
+    upload(ctx, world);
     const rtow_camera_f64 cam = camera.flat();
     check(rtow_set_camera_f64(ctx, &cam), "rtow_set_camera_f64");
     check(rtow_render(ctx, img.width, img.height, samplesPerPixel, maxDepth, seed, nullptr, img.height,
@@ -74,14 +80,12 @@ inline std::vector<uint8_t> renderMulti(const Image& img, const std::string& f, 
   std::vector<uint8_t> rgb((size_t)img.width * (size_t)img.height * 3);
   auto destroyAll = [&]() { for (rtow_ctx* c : ctxs) rtow_destroy(c); };
   try {
-    const HittablesList::Flat s = world.flatten();
     const rtow_camera_f64 cam = camera.flat();
     for (int device : devices) {
       rtow_ctx* ctx = nullptr;
       check(rtow_create(device, &ctx), "rtow_create");
       ctxs.push_back(ctx);
-      check(rtow_set_scene_f64(ctx, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
-                           s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene_f64");
+      upload(ctx, world);
       check(rtow_set_camera_f64(ctx, &cam), "rtow_set_camera_f64");
     }
     check(rtow_render_multi(ctxs.data(), (int)ctxs.size(), img.width, img.height, samplesPerPixel, maxDepth, seed, 4,
@@ -103,11 +107,7 @@ class Device {
   ~Device() { rtow_destroy(ctx_); }
   Device(const Device&) = delete;
   Device& operator=(const Device&) = delete;
-  void setWorld(const HittablesList& world) {
-    const HittablesList::Flat s = world.flatten();
-    check(rtow_set_scene_f64(ctx_, world.len(), s.cx.data(), s.cy.data(), s.cz.data(), s.radius.data(), s.kind.data(),
-                             s.albedo.data(), s.fuzz.data(), s.ir.data()), "rtow_set_scene_f64");
-  }
+  void setWorld(const HittablesList& world) { upload(ctx_, world); }
   void setCamera(const Camera& camera) {
     const rtow_camera_f64 cam = camera.flat();
     check(rtow_set_camera_f64(ctx_, &cam), "rtow_set_camera_f64");
@@ -139,6 +139,23 @@ inline bool hit(const HittablesList& h, Device& dev, const Ray& r, double t_min,
   rec.mat = s.mat;
   rec.index = id;
   return true;
+}
+
+// hit*(s: Sphere, r, t_min, t_max, rec)  (hitrecord.nim:55-79): one sphere is a one-entry list.  `dev` is given that
+// list (whatever world it held before is replaced).
+inline bool hit(const Sphere& s, Device& dev, const Ray& r, double t_min, double t_max, HitRecord& rec) {
+  HittablesList one = initHittables(0);
+  one.add(s);
+  dev.setWorld(one);
+  return hit(one, dev, r, t_min, t_max, rec);
+}
+
+// hit*(h: Hittable, r, t_min, t_max, rec)  (hittables.nim:75-77): case h.kind of htSphere: h.hSphere.hit(...)
+inline bool hit(const Hittable& h, Device& dev, const Ray& r, double t_min, double t_max, HitRecord& rec) {
+  switch (h.kind) {
+    case htSphere: return hit(h.hSphere, dev, r, t_min, t_max, rec);
+  }
+  throw std::runtime_error("hit: Hittable of unknown kind " + std::to_string((int)h.kind));
 }
 
 // scatter*(m, r_in, rec, attenuation, scattered)  (hitrecord.nim:127-132); draws from the stream of path

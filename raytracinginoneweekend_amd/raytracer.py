@@ -66,8 +66,18 @@ class Renderer:
         if not (len(cx) == len(cy) == len(cz) == len(kind) == len(fuzz) == len(ir) == n and albedo.shape == (n, 3)):
             raise ValueError("setWorld: arrays of unequal length")
         p = lambda a: a.ctypes.data if n else None  # noqa: E731
-        call = self._lib.rtow_set_scene if binary32 else self._lib.rtow_set_scene_f64
-        self._check(call(self._h, n, p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo), p(fuzz), p(ir)))
+        hk = world.get("hittable_kind")
+        if hk is not None and not binary32:
+            # the list as the reference holds it, Hittable.kind included (hittables.nim:4-8): the library refuses any
+            # kind but htSphere
+            hk = np.ascontiguousarray(hk, dtype=np.uint8)
+            if len(hk) != n:
+                raise ValueError("setWorld: arrays of unequal length")
+            self._check(self._lib.rtow_set_hittables(self._h, n, p(hk), p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo),
+                                                     p(fuzz), p(ir)))
+        else:
+            call = self._lib.rtow_set_scene if binary32 else self._lib.rtow_set_scene_f64
+            self._check(call(self._h, n, p(cx), p(cy), p(cz), p(rad), p(kind), p(albedo), p(fuzz), p(ir)))
         self.n_spheres = n
 
     def setCamera(self, camera):
@@ -207,12 +217,26 @@ class Renderer:
         self._check(self._lib.rtow_get_stats(self._h, C.byref(s)))
         return {"ray_segments": s.ray_segments, "paths": s.paths, "trace_ms": s.trace_ms,
                 "total_ms": s.total_ms, "n_spheres": s.n_spheres, "n_big": s.n_big,
-                "shader_clock_mhz": s.shader_clock_mhz}
+                "shader_clock_mhz": s.shader_clock_mhz, "gather_path": s.gather_path}
 
     def stream(self):
         p = C.c_void_p()
         self._check(self._lib.rtow_get_stream(self._h, C.byref(p)))
         return p.value
+
+
+def multiPlan(width, height, n_ctx, tile=4, lib=None):
+    """The dealing of rows behind renderMulti (rtow_multi_plan; no GPU is touched): returns
+    (ctx_of_row int32 [height], index_in_ctx int32 [height], rows_per_ctx int32 [n_ctx], slot_bytes)."""
+    L = lib if lib is not None else _lib.lib()
+    ctx_of_row = np.full(max(height, 0), -1, np.int32)
+    index_in_ctx = np.full(max(height, 0), -1, np.int32)
+    rows_per_ctx = np.full(max(n_ctx, 0), -1, np.int32)
+    slot = C.c_uint64(0)
+    _lib.check(L.rtow_multi_plan(width, height, n_ctx, tile, ctx_of_row.ctypes.data if height > 0 else None,
+                                 index_in_ctx.ctypes.data if height > 0 else None,
+                                 rows_per_ctx.ctypes.data if n_ctx > 0 else None, C.byref(slot)), L)
+    return ctx_of_row, index_in_ctx, rows_per_ctx, slot.value
 
 
 def renderMulti(renderers, width, height, samplesPerPixel, maxDepth, seed=RENDER_SEED, tile=4):
@@ -235,17 +259,28 @@ _shared = {"renderer": None, "world": None, "camera": None}
 
 
 def _shared_renderer(world=None, camera=None):
-    """The module's own Renderer (device 0), holding `world` / `camera` (uploaded again only when another
-    object is passed)."""
+    """The module's own Renderer (device 0), holding `world` / `camera`.  The reference's procs take the list as
+    `var HittablesList` and always see its current contents, so the list is flattened on every call and uploaded
+    again whenever the flattened values differ from what the device holds - a sphere replaced or edited in place
+    at the same length counts (these wrappers are one-ray slow paths; flattening 484 spheres costs about a
+    millisecond).  The camera is compared field by field likewise."""
     if _shared["renderer"] is None:
         _shared["renderer"] = Renderer(0)
     r = _shared["renderer"]
-    if world is not None and (_shared["world"] is not world or _shared.get("world_len") != len(world)):
-        r.setWorld(world)
-        _shared["world"], _shared["world_len"] = world, len(world)
-    if camera is not None and _shared["camera"] is not camera:
-        r.setCamera(camera)
-        _shared["camera"] = camera
+    if world is not None:
+        flat = world.flatten() if isinstance(world, HittablesList) else world
+        key = tuple(np.ascontiguousarray(flat[k]).tobytes() for k in sorted(flat))
+        if _shared["world"] != key:
+            _shared["world"] = None      # a refused upload leaves no claim about what the device holds
+            r.setWorld(flat)
+            _shared["world"] = key
+    if camera is not None:
+        s = camera.to_struct() if isinstance(camera, Camera) else camera
+        key = bytes(s)
+        if _shared["camera"] != key:
+            _shared["camera"] = None
+            r.setCamera(s)
+            _shared["camera"] = key
     return r
 
 
@@ -263,7 +298,11 @@ def rayColor(r, world, depth, seed=RENDER_SEED, index=0):
 def hit(world, r, t_min, t_max, rec):
     """hit*(h: var HittablesList, r: Ray, t_min, t_max: float, rec: var HitRecord): bool
     (hittables.nim:79-88).  The closest-hit search runs on the GPU; the record is completed here as
-    Sphere.hit does (hitrecord.nim:73-77)."""
+    Sphere.hit does (hitrecord.nim:73-77).  A Hittable (hittables.nim:75-77) or a Sphere (hitrecord.nim:55)
+    in place of the list is answered as a one-entry list (hittables.hit does the dispatch)."""
+    if not isinstance(world, HittablesList):
+        from . import hittables
+        return hittables.hit(world, r, t_min, t_max, rec)
     dev = _shared_renderer(world=world)
     _, hid, t = dev.traceRays([list(r.orig)], [list(r.dir)], 0, t_min=t_min, t_max=t_max, want_color=False)
     if hid[0] < 0:

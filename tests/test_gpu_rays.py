@@ -149,6 +149,117 @@ def test_reference_signatures(oracle, book_scene):
     assert max(abs(got[k] - f[k]) for k in range(3)) < 1e-4
 
 
+def test_hit_overloads_for_one_object(oracle):
+    """hit*(s: Sphere, ...) (hitrecord.nim:55-79) and hit*(h: Hittable, ...) (hittables.nim:75-77): the record of a
+    one-object query equals the FP64 restatement's Sphere.hit - t, p, normal, frontFace - for rays from outside,
+    from inside, with a negative radius, and for a restricted [t_min, t_max]."""
+    from raytracinginoneweekend_amd import hittables as HT
+    from raytracinginoneweekend_amd.basetypes import color, initRay, point, vec3
+    from raytracinginoneweekend_amd.hitrecord import HitRecord, Sphere, initDielectric, initLambertian, initMaterial
+    L = oracle.lib()
+    rng = np.random.default_rng(21)
+    cases = [(Sphere(point(0.3, 0.1, -2.0), 0.75, initMaterial(initLambertian(color(0.2, 0.3, 0.4)))), (0.001, math.inf)),
+             (Sphere(point(0.0, 0.0, 0.0), 3.0, initMaterial(initDielectric(1.5))), (0.001, math.inf)),       # rays start inside
+             (Sphere(point(-0.2, 0.0, -1.5), -0.6, initMaterial(initDielectric(1.5))), (0.001, math.inf)),    # normal flipped
+             (Sphere(point(0.0, 0.0, -2.0), 0.9, initMaterial(initLambertian(color(0.5, 0.5, 0.5)))), (1.5, 4.0))]
+    n_hits = 0
+    for sphere, (t_min, t_max) in cases:
+        arr, _ = oracle.spheres_from_arrays([list(sphere.center)], [sphere.radius], [sphere.mat.flat()[0]],
+                                            [sphere.mat.flat()[1]], [sphere.mat.flat()[2]], [sphere.mat.flat()[3]])
+        for i in range(40):
+            o = rng.normal(0.0, 0.4, 3)
+            d = (np.array([0.0, 0.0, -1.0]) + rng.normal(0.0, 0.5, 3)) * math.exp(rng.uniform(-2.0, 2.0))
+            ray = initRay(point(*o), vec3(*d))
+            tt, pp, nn, ff = C.c_double(0), (C.c_double * 3)(), (C.c_double * 3)(), C.c_int(0)
+            want = L.orc_ref64_sphere_hit(arr, _dp(o), _dp(d), t_min, t_max, C.byref(tt), pp, nn, C.byref(ff))
+            for obj in (sphere, HT.Hittable(HT.htSphere, sphere)):
+                rec = HitRecord()
+                assert HT.hit(obj, ray, t_min, t_max, rec) == bool(want), (i, want)
+                if want:
+                    assert rec.t == tt.value and list(rec.p) == list(pp) and list(rec.normal) == list(nn)
+                    assert rec.frontFace == bool(ff.value) and rec.mat is sphere.mat
+            n_hits += want
+    assert n_hits > 60
+
+
+def test_list_with_unknown_hittable_kind_is_refused(gpu_renderer, oracle, book_scene):
+    """rtow_set_hittables takes the list as the reference holds it - Hittable.kind per entry (hittables.nim:4-8) -
+    and has, like hit*(h: Hittable) (hittables.nim:75-77), one branch: htSphere.  Another kind is an error that
+    names the entry, and the context keeps the world it had."""
+    from raytracinginoneweekend_amd import _lib, hittables as HT
+    R = _R()
+    arr, n = book_scene
+    world = R.randomScene()
+    gpu_renderer.setWorld(world)        # through rtow_set_hittables: the flattened list carries the kinds
+    gpu_renderer.setCamera(R.bookCamera(1.5))
+    before = gpu_renderer.renderRows(60, 40, 2, 50, want_accum=True)
+    ref = oracle.render_mirror32(arr, n, oracle.book_camera(1.5), 60, 40, 2, 50)
+    assert (before[1] == ref[1]).all()
+    broken = R.randomScene()
+    broken[17] = HT.Hittable(1, broken[17].hSphere)
+    with pytest.raises(_lib.RtowError) as e:
+        gpu_renderer.setWorld(broken)
+    assert e.value.status == -1 and "entry 17" in str(e.value) and "htSphere" in str(e.value)
+    after = gpu_renderer.renderRows(60, 40, 2, 50, want_accum=True)
+    assert (after[1] == before[1]).all()
+    with pytest.raises(ValueError):      # the host-side dispatch refuses it as well
+        HT.hit(broken[17], R.getRay(R.bookCamera(1.5), 0.5, 0.5), 0.001, math.inf, R.HitRecord())
+
+
+def test_world_edited_in_place_is_seen_by_the_per_ray_procs():
+    """The reference's procs take `var HittablesList` and see its current contents.  A sphere replaced, or edited
+    in place, at the same list length must reach the device before the next query."""
+    from raytracinginoneweekend_amd.basetypes import color, initRay, point, vec3
+    from raytracinginoneweekend_amd.hitrecord import HitRecord, Sphere, initLambertian, initMaterial
+    from raytracinginoneweekend_amd.hittables import initHittables
+    R = _R()
+    world = initHittables(0)
+    world.add(Sphere(point(0, 0, -3), 0.5, initMaterial(initLambertian(color(0.5, 0.5, 0.5)))))
+    world.add(Sphere(point(0, 0, -6), 0.5, initMaterial(initLambertian(color(0.5, 0.5, 0.5)))))
+    ray = initRay(point(0, 0, 0), vec3(0, 0, -1))
+    rec = HitRecord()
+    assert R.hit(world, ray, 0.001, math.inf, rec) and rec.index == 0 and rec.t == 2.5
+    world[0].hSphere.center = point(5, 0, -3)                    # edited in place: out of the ray's way
+    assert R.hit(world, ray, 0.001, math.inf, rec) and rec.index == 1 and rec.t == 5.5
+    world[1] = type(world[1])(0, Sphere(point(0, 0, -8), 1.0))   # replaced at the same length
+    assert R.hit(world, ray, 0.001, math.inf, rec) and rec.index == 1 and rec.t == 7.0
+    world[1].hSphere.radius = 2.0
+    assert R.hit(world, ray, 0.001, math.inf, rec) and rec.t == 6.0
+    assert list(R.rayColor(initRay(point(0, 0, 0), vec3(0, 1, 0)), world, 5)) == [0.5, 0.7, 1.0]
+
+
+def test_directions_far_outside_binary32_range(gpu_renderer, oracle, book_scene):
+    """hit* takes un-normalised binary64 directions (camera.nim:38-39 never normalises).  A direction whose
+    length under- or overflows binary32 must still find the reference's hit: index equal, t equal (t is in units of
+    |direction|, so it scales inversely)."""
+    arr, n = book_scene
+    R = _R()
+    gpu_renderer.setWorld(R.randomScene())
+    L = oracle.lib()
+    rng = np.random.default_rng(31)
+    o, d = _rays(rng, 400)
+    _, hid0, _ = gpu_renderer.traceRays(o, d, 0, want_color=False)
+    for scale in (1e-25, 1e25, 2.0 ** -70, 2.0 ** 90, 1e-150, 1e140):
+        ds = d * scale
+        _, hid, t = gpu_renderer.traceRays(o, ds, 0, t_min=0.001 / scale, want_color=False)
+        hits = 0
+        for i in range(len(o)):
+            tt = C.c_double(0.0)
+            want = L.orc_ref64_world_hit(arr, n, _dp(o[i]), _dp(np.ascontiguousarray(ds[i])), 0.001 / scale, math.inf, C.byref(tt))
+            assert hid[i] == want, (scale, i, hid[i], want)
+            if want >= 0:
+                assert t[i] == tt.value, (scale, i)
+                hits += 1
+        assert hits > 150
+        if scale in (2.0 ** -70, 2.0 ** 90):   # powers of two change no rounding anywhere: the same hits as unscaled
+            assert (hid == hid0).all()
+    # colours: the sky gradient of a miss uses the binary64 unit direction, whatever the length
+    up = np.array([[0.0, 5.0, 0.0]])
+    for scale in (1e-30, 1.0, 1e30):
+        col, _, _ = gpu_renderer.traceRays(up, np.array([[0.0, scale, 0.0]]), 50)
+        assert list(col[0]) == [0.5, 0.7, 1.0]
+
+
 def test_cpp_host_per_ray_procs(oracle, book_scene):
     """getRay, hit, rayColor and scatter of the compiled host (raytracinginoneweekend_amd/host) through its CLI."""
     import os
@@ -183,6 +294,36 @@ def test_cpp_host_per_ray_procs(oracle, book_scene):
             nrm = np.array([float(x) for x in v[12:15]])
             ok32 = L.orc_mirror32_scatter(C.byref(arr[want]), _dp(d), _dp(nrm), int(v[15]), 0xE7, 0, a32, o32)
             assert int(v[19]) == ok32 and [float(x) for x in v[20:23]] == list(a32) and [float(x) for x in v[23:26]] == list(o32)
+
+
+def test_cpp_host_one_object_hits_and_unknown_kind(oracle, book_scene):
+    """The compiled host's hit(Sphere) (hitrecord.nim:55) and hit(Hittable) (hittables.nim:75-77) overloads against
+    the FP64 restatement's Sphere.hit, and its upload of a list whose entry has a kind the reference lacks."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    arr, n = book_scene
+    L = oracle.lib()
+    exe = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "rtow_raytracer")
+    seen = 0
+    for (s_, t_), j in (((0.5, 0.45), 482), ((0.5, 0.45), 0), ((0.2, 0.9), 0), ((0.52, 0.5), 481)):
+        lines = subprocess.check_output([exe, "--probe", repr(s_), repr(t_), "--probe-one", str(j), "--depth", "2"],
+                                        text=True).strip().splitlines()
+        assert len(lines) == 3
+        v = lines[0].split()
+        o, d = np.array([float(x) for x in v[0:3]]), np.array([float(x) for x in v[3:6]])
+        tt, pp, nn, ff = C.c_double(0), (C.c_double * 3)(), (C.c_double * 3)(), C.c_int(0)
+        want = L.orc_ref64_sphere_hit(C.byref(arr[j]), _dp(o), _dp(d), 0.001, math.inf, C.byref(tt), pp, nn, C.byref(ff))
+        for line in lines[1:]:
+            w = line.split()
+            assert int(w[0]) == want, (j, line)
+            if want:
+                assert float(w[1]) == tt.value and [float(x) for x in w[2:5]] == list(pp)
+                assert [float(x) for x in w[5:8]] == list(nn) and int(w[8]) == ff.value
+        seen += want
+    assert seen >= 2
+    bad = subprocess.run([exe, "--width", "60", "--spp", "1", "--corrupt-kind", "5", "--out", os.devnull], capture_output=True, text=True)
+    assert bad.returncode == 1 and "entry 5" in bad.stderr and "htSphere" in bad.stderr
 
 
 def test_ray_entry_point_errors(gpu_renderer):

@@ -170,6 +170,61 @@ def test_tile_rows_partition():
         multigpu.tile_rows(10, 2, 2)
 
 
+def test_multi_plan_row_and_slot_arithmetic():
+    """rtow_multi_plan is the dealing rtow_render_multi and its RCCL gather use (no GPU involved): every row has
+    one owner, the owners' rows keep image order, the slot is the largest share rounded up to 256 bytes, and
+    packing every context's rows into its slot and reading them back through the plan reproduces the image -
+    with an uneven last tile, contexts left without rows, more contexts than tiles, one context."""
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for w, h, n_ctx, tile in ((150, 101, 5, 7), (1200, 800, 8, 4), (7, 5, 8, 4), (33, 9, 3, 4), (16, 64, 1, 4),
+                              (5, 3, 4, 1), (9, 10, 2, 200), (1200, 800, 3, 4), (2, 2, 16, 3)):
+        ctx_of_row, index_in_ctx, rows_per_ctx, slot = R.multiPlan(w, h, n_ctx, tile)
+        assert ((ctx_of_row == (np.arange(h) // tile) % n_ctx)).all()
+        assert rows_per_ctx.sum() == h and slot % 256 == 0 and slot >= 3 * w * rows_per_ctx.max() > slot - 256
+        for k in range(n_ctx):
+            mine = np.flatnonzero(ctx_of_row == k)
+            assert len(mine) == rows_per_ctx[k]
+            assert (index_in_ctx[mine] == np.arange(len(mine))).all()          # image order inside a context
+            assert (mine == multigpu.tile_rows(h, n_ctx, k, tile)).all()        # what the per-process host deals
+        if n_ctx > (h + tile - 1) // tile:
+            assert (rows_per_ctx[(h + tile - 1) // tile:] == 0).all()           # contexts without a tile
+        image = rng.integers(0, 256, (h, 3 * w), dtype=np.uint8)
+        buf = np.full(slot * n_ctx, 0xEE, np.uint8)                             # the gather buffer: one slot per context
+        for k in range(n_ctx):
+            rows = multigpu.tile_rows(h, n_ctx, k, tile)
+            buf[slot * k: slot * k + 3 * w * len(rows)] = image[rows].reshape(-1)
+        back = np.stack([buf[slot * ctx_of_row[y] + 3 * w * index_in_ctx[y]:][: 3 * w] for y in range(h)])
+        assert (back == image).all()
+    # any output may be NULL; bad arguments are refused
+    only_slot = C.c_uint64(0)
+    assert L.rtow_multi_plan(10, 10, 2, 4, None, None, None, C.byref(only_slot)) == 0 and only_slot.value == 256
+    assert L.rtow_multi_plan(10, 0, 2, 4, None, None, None, C.byref(only_slot)) == 0 and only_slot.value == 0
+    for bad in ((0, 10, 2, 4), (10, -1, 2, 4), (10, 10, 0, 4), (10, 10, 2, 0)):
+        assert L.rtow_multi_plan(*bad, None, None, None, None) == -1
+    assert b"rtow_multi_plan" in L.rtow_last_error()
+
+
+def test_hittable_variant_surface():
+    """Hittable (hittables.nim:4-8) keeps its kind through flatten, and hit*(h: Hittable) (hittables.nim:75-77)
+    refuses a kind its case statement has no branch for - before anything reaches a device."""
+    s = HR.Sphere(B.point(0, 0, -1), 0.5)
+    h = HT.initHittables(0)
+    h.add(s)
+    h.add(HT.Hittable(7, s))
+    f = h.flatten()
+    assert f["hittable_kind"].dtype == np.uint8 and list(f["hittable_kind"]) == [HT.htSphere, 7]
+    assert HT.htSphere == _lib.HT_SPHERE == 0
+    with pytest.raises(ValueError) as e:
+        HT.hit(HT.Hittable(7, s), B.initRay(B.point(0, 0, 0), B.vec3(0, 0, -1)), 0.001, 1e9, HR.HitRecord())
+    assert "htSphere" in str(e.value)
+    L = _lib.lib()
+    assert L.rtow_set_hittables(None, 0, None, None, None, None, None, None, None, None, None) == -1
+    bad = np.array([0, 3], np.uint8)   # refused by kind before the context is looked at
+    assert L.rtow_set_hittables(None, 2, bad.ctypes.data, None, None, None, None, None, None, None, None) == -1
+    assert b"HittableKind 3" in L.rtow_last_error() and b"entry 1" in L.rtow_last_error()
+
+
 def test_package_surface():
     assert {"basetypes", "camera", "hitrecord", "hittables", "raytracer"} <= set(rt.__all__)
     assert callable(rt.render) and callable(R.writeColor) and callable(cam_mod.initCamera)
