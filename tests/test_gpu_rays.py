@@ -306,7 +306,10 @@ def test_cpp_host_one_object_hits_and_unknown_kind(oracle, book_scene):
     L = oracle.lib()
     exe = os.path.join(ROOT, "raytracinginoneweekend_amd", "lib", "rtow_raytracer")
     seen = 0
-    for (s_, t_), j in (((0.5, 0.45), 482), ((0.5, 0.45), 0), ((0.2, 0.9), 0), ((0.52, 0.5), 481)):
+    # (s, t) of a camera ray and a list entry: the sphere it hits in the whole list, the ground it would hit behind
+    # that sphere, the big metal sphere, the ground from a pixel that sees it, and two entries the ray misses
+    for (s_, t_), j in (((0.5, 0.45), 298), ((0.5, 0.45), 0), ((0.52, 0.5), 483), ((0.5, 0.2), 0), ((0.2, 0.9), 0),
+                        ((0.52, 0.5), 481)):
         lines = subprocess.check_output([exe, "--probe", repr(s_), repr(t_), "--probe-one", str(j), "--depth", "2"],
                                         text=True).strip().splitlines()
         assert len(lines) == 3
@@ -321,7 +324,7 @@ def test_cpp_host_one_object_hits_and_unknown_kind(oracle, book_scene):
                 assert float(w[1]) == tt.value and [float(x) for x in w[2:5]] == list(pp)
                 assert [float(x) for x in w[5:8]] == list(nn) and int(w[8]) == ff.value
         seen += want
-    assert seen >= 2
+    assert seen == 4
     bad = subprocess.run([exe, "--width", "60", "--spp", "1", "--corrupt-kind", "5", "--out", os.devnull], capture_output=True, text=True)
     assert bad.returncode == 1 and "entry 5" in bad.stderr and "htSphere" in bad.stderr
 
