@@ -80,6 +80,21 @@ static __device__ __forceinline__ bool guard_ok(int site, long long v, long long
 #define RTOW_GUARDED(site, v, limit) true
 #endif
 
+// A kernel argument read from the argument segment at the point of use (one scalar load) instead of being kept in a
+// scalar register for the life of the wave.  The trace kernel has more wave-uniform state than scalar registers:
+// what does not fit is parked in the lanes of a vector register and fetched back with v_readlane - VALU
+// instructions in a kernel bound by VALU issue.  The empty asm makes the base address opaque, so the load cannot
+// be hoisted out of the loop it sits in.
+template <typename T>
+static __device__ __forceinline__ T karg_load(size_t offset) {
+  typedef const char __attribute__((address_space(4)))* base_ptr;
+  typedef const T __attribute__((address_space(4)))* field_ptr;
+  base_ptr base = (base_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(base));
+  return *(field_ptr)(base + offset);
+}
+#define KARG(field) karg_load<decltype(TraceParams::field)>(offsetof(TraceParams, field))
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f8v __attribute__((ext_vector_type(8)));
@@ -226,14 +241,12 @@ template <bool SHORT> struct WaveLds {
 };
 
 // What the exact tests of a PRIMARY scan need: the binary64 camera rays of the wave (LDS, six
-// doubles per lane, field-major: ox oy oz dx dy dz), the binary64 sphere table, and the list
-// index of every lane's closest hit so far (+1; 0 = none) beside its 64-bit key (the bits of t).
+// doubles per lane, field-major: ox oy oz dx dy dz) and the list index of every lane's closest hit so
+// far (+1; 0 = none) beside its 64-bit key (the bits of t).  The binary64 sphere table is a kernel
+// argument, read where it is used.
 struct PrimaryCtx {
   lds_f64_ptr rays;
-  const double4* geom64;
-  const float* slab;   // -r^2 per table entry for the slab test (tables whose groups have no room for it), else unused
   lds_u32_ptr best_id;
-  int n_list;   // entries of geom64 (debug builds check indices against it)
 };
 
 template <bool SHORT>
@@ -373,12 +386,12 @@ static __device__ __forceinline__ void cand_drain(CandList<SHORT>& c, ExactPtr e
     if (PRIMARY) {
       bool valid = false;
       unsigned long long tb = ~0ull;
-      if (has && RTOW_GUARDED(0, j, pc.n_list)) {
+      if (has && RTOW_GUARDED(0, j, KARG(n_list))) {
         const lds_f64_ptr r = pc.rays + owner;
         const double dx = r[192], dy = r[256], dz = r[320];
         const double a = dx * dx + dy * dy + dz * dz;   // length_squared (basetypes.nim:88)
         double root;
-        valid = sphere_hit_f64(r[0], r[64], r[128], dx, dy, dz, a, pc.geom64[j], root);
+        valid = sphere_hit_f64(r[0], r[64], r[128], dx, dy, dz, a, KARG(geom64)[j], root);
         tb = (unsigned long long)__double_as_longlong(root);
       }
       // t > 0, so the bit patterns order like the values.  A lane that lowers the key voids the index
@@ -491,7 +504,7 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   static_assert(AXIS < 0 || PRIMARY, "the slab test is for the camera rays");
   if (n_groups <= 0) return;
   constexpr bool SLAB = AXIS >= 0;   // the slab test runs where the wave's rays are one pixel's camera rays
-  const slab_ptr slab = (slab_ptr)(uintptr_t)pc.slab;
+  const slab_ptr slab = (SLAB && !K_LDS) ? (slab_ptr)(uintptr_t)KARG(geom_slab) : nullptr;
   ScanRay r = scan_ray(o, u, cmax);
   if (!live) { r.ozt.y = INFINITY; pre.y = -INFINITY; }
   // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
@@ -595,8 +608,8 @@ static __device__ __forceinline__ void set_tag(SumCache& c, uint32_t slot, uint3
   c.tag[2] = slot == 2u ? pix : c.tag[2]; c.tag[3] = slot == 3u ? pix : c.tag[3];
 }
 
-static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum, const SumCache& c, uint32_t slot,
-                                                       uint32_t pix, uint32_t lane) {
+static __device__ __forceinline__ void sum_cache_evict(const SumCache& c, uint32_t slot, uint32_t pix, uint32_t lane) {
+  unsigned long long* const accum = KARG(accum);
   // LDS serves one wave's requests in order: the adds of earlier instructions are in the words read here
   lds_order();
 #ifdef RTOW_PROFILE_COUNTERS
@@ -611,7 +624,7 @@ static __device__ __forceinline__ void sum_cache_evict(unsigned long long* accum
 }
 
 // Must be called by all 64 lanes together; lanes with `want` set add (acc_r, acc_g, acc_b), in sum units, to pixel accpix.
-static __device__ __forceinline__ void flush_sums(unsigned long long* accum, SumCache& c, bool want, uint32_t accpix,
+static __device__ __forceinline__ void flush_sums(SumCache& c, bool want, uint32_t accpix,
                                                   uint64_t acc_r, uint64_t acc_g, uint64_t acc_b, uint32_t lane) {
   uint64_t todo = __ballot(want);
   while (todo != 0) {
@@ -625,7 +638,7 @@ static __device__ __forceinline__ void flush_sums(unsigned long long* accum, Sum
       slot = c.victim;
       c.victim = (c.victim + 1u) & (kSumSlots - 1u);
       const uint32_t held = tag_of(c, slot);
-      if (held != kNoPixel) sum_cache_evict(accum, c, slot, held, lane);
+      if (held != kNoPixel) sum_cache_evict(c, slot, held, lane);
       set_tag(c, slot, pix);
     }
     const bool mine = want && accpix == pix;
@@ -638,10 +651,10 @@ static __device__ __forceinline__ void flush_sums(unsigned long long* accum, Sum
   }
 }
 
-static __device__ __forceinline__ void sum_cache_drain(unsigned long long* accum, SumCache& c, uint32_t lane) {
+static __device__ __forceinline__ void sum_cache_drain(SumCache& c, uint32_t lane) {
   for (uint32_t slot = 0; slot < kSumSlots; ++slot) {
     const uint32_t held = c.tag[slot];
-    if (held != kNoPixel) sum_cache_evict(accum, c, slot, held, lane);
+    if (held != kNoPixel) sum_cache_evict(c, slot, held, lane);
     c.tag[slot] = kNoPixel;
   }
 }
@@ -682,9 +695,6 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   cand.lane = lane;
   PrimaryCtx pc;
   pc.rays = (lds_f64_ptr)(const double*)pool;
-  pc.geom64 = P.geom64;
-  pc.slab = P.geom_slab;
-  pc.n_list = P.n_list;
   pc.best_id = (lds_u32_ptr)(wave_lds + L::kIds);
   SumCache sums;
   {
@@ -763,7 +773,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           tb = __uint_as_float(pool[(kPoolT + 2) * 64 + entry]);
           g.x0 = pool[kPoolX0 * 64 + entry]; g.key1 = pool[kPoolKey1 * 64 + entry];
           prev = (int)pool[kPoolPrev * 64 + entry];
-          depth = P.max_depth - 1;
+          depth = KARG(max_depth) - 1;
           alive = true;
         }
         RTOW_COUNT(23, min(cnt, avail));
@@ -776,18 +786,18 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       if (e_next >= e_end && !exhausted) {
         // guided self-scheduling: a quarter of an even share of what was left when this wave
         // last looked, clamped to [chunk_min, chunk_max] and rounded down to whole wavefronts
-        uint32_t want = P.chunk_max;
-        const unsigned long long left_seen = P.total_paths - seen;
-        if (left_seen < 4ull * P.n_waves * P.chunk_max) {
-          want = ((uint32_t)left_seen / (4u * P.n_waves)) & ~63u;
-          want = want < P.chunk_min ? P.chunk_min : want;
+        uint32_t want = KARG(chunk_max);
+        const unsigned long long left_seen = KARG(total_paths) - seen;
+        if (left_seen < 4ull * KARG(n_waves) * KARG(chunk_max)) {
+          want = ((uint32_t)left_seen / (4u * KARG(n_waves))) & ~63u;
+          want = want < KARG(chunk_min) ? KARG(chunk_min) : want;
         }
         unsigned long long first = 0;
-        if (lane == 0) first = atomicAdd(P.path_counter, (unsigned long long)want);
+        if (lane == 0) first = atomicAdd(KARG(path_counter), (unsigned long long)want);
         // (the builtin returns int: widen through uint32_t, or a low word >= 2^31 sign-extends over the high word)
         first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(first >> 32)) << 32) |
                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first);
-        if (first >= P.total_paths) {
+        if (first >= KARG(total_paths)) {
 #ifdef RTOW_PROFILE_TIMELINE
           {
             const unsigned long long live_ = __popcll(__ballot(alive));
@@ -815,15 +825,15 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
             else __builtin_amdgcn_s_setprio(0);
             my_paths += (float)want;
           }
-          const unsigned long long left = P.total_paths - first;
+          const unsigned long long left = KARG(total_paths) - first;
           // Pixels are handed out from the LAST pixel of the row list backwards, so a frame ends on its
           // top rows.  The waves retire only when their longest path has ended, and in the scenes this
           // renderer is used on the top of the frame is sky (one segment per path) while the bottom is
           // ground and spheres (paths of up to max_depth segments): finishing on cheap paths cuts the
           // time the grid spends draining from milliseconds to one iteration.
-          const uint32_t p_seq = (uint32_t)(first / (uint32_t)P.spp);
-          s_base = (uint32_t)(first - (unsigned long long)p_seq * (uint32_t)P.spp);
-          p_base = (uint32_t)P.n_rows * (uint32_t)P.W - 1u - p_seq;
+          const uint32_t p_seq = (uint32_t)(first / (uint32_t)KARG(spp));
+          s_base = (uint32_t)(first - (unsigned long long)p_seq * (uint32_t)KARG(spp));
+          p_base = (uint32_t)KARG(n_rows) * (uint32_t)P.W - 1u - p_seq;
           r_base = p_base / (uint32_t)P.W;
           i_base = p_base - r_base * (uint32_t)P.W;
           e_next = 0;
@@ -852,13 +862,13 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       const bool gen = lane < n_gen;
       const uint32_t e = s_base + e_next + (gen ? lane : 0u);
       uint32_t dp, sample;
-      if ((uint32_t)P.spp >= P.chunk_max) {
-        dp = e >= (uint32_t)P.spp ? 1u : 0u;
-        sample = e - (dp ? (uint32_t)P.spp : 0u);
+      if ((uint32_t)KARG(spp) >= KARG(chunk_max)) {
+        dp = e >= (uint32_t)KARG(spp) ? 1u : 0u;
+        sample = e - (dp ? (uint32_t)KARG(spp) : 0u);
       } else {
         // e < 2 * chunk_max + spp and spp < chunk_max here: exact (2^32 / 1 does not fit inv_spp)
-        dp = P.spp == 1 ? e : __umulhi(e, P.inv_spp);
-        sample = e - dp * (uint32_t)P.spp;
+        dp = KARG(spp) == 1 ? e : __umulhi(e, KARG(inv_spp));
+        sample = e - dp * (uint32_t)KARG(spp);
       }
       double* const rays = (double*)pool;   // the pool is empty during this iteration: its memory holds the rays
       {
@@ -871,8 +881,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         uint32_t r = r_base;
         int ci = (int)i_base - (int)dp;
         while (ci < 0) { ci += P.W; --r; }
-        const int y = P.rows ? P.rows[r] : (int)r;
-        Stream g2 = stream_begin(P.seed_lo, P.seed_hi, (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + P.sample_base);
+        const int y = KARG(rows) ? KARG(rows)[r] : (int)r;
+        Stream g2 = stream_begin(KARG(seed_lo), KARG(seed_hi), (uint32_t)y * (uint32_t)P.W + (uint32_t)ci, sample + KARG(sample_base));
         // raytracer.nim:41-42: u before v, divisors W-1 and H-1, j counted from the bottom row
         const double xi1 = (double)(draw_u32(g2) >> 8) * 0x1p-24, xi2 = (double)(draw_u32(g2) >> 8) * 0x1p-24;
         const double cs = ((double)ci + xi1) / (double)(P.W - 1);
@@ -898,11 +908,11 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         const double a64 = d64[0] * d64[0] + d64[1] * d64[1] + d64[2] * d64[2];   // length_squared (basetypes.nim:88)
         double closest = INFINITY;
         int pid = -1;
-        for (int k = 0; k < P.n_big; ++k) {
-          const int j = P.big[k].index;
+        for (int k = 0; k < KARG(n_big); ++k) {
+          const int j = KARG(big)[k].index;
           double root;
-          if (RTOW_GUARDED(2, j, P.n_list) &&
-              sphere_hit_f64(o64[0], o64[1], o64[2], d64[0], d64[1], d64[2], a64, P.geom64[j], root) && !(closest < root)) {
+          if (RTOW_GUARDED(2, j, KARG(n_list)) &&
+              sphere_hit_f64(o64[0], o64[1], o64[2], d64[0], d64[1], d64[2], a64, KARG(geom64)[j], root) && !(closest < root)) {
             closest = root;
             pid = j;
           }
@@ -924,9 +934,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         typedef const float __attribute__((address_space(4)))* karg_f32_ptr;
         static_assert(offsetof(TraceParams, rmax) == sizeof(CameraParams64), "rmax follows the camera");
         f2v pre = {0.0f, 0.0f};
-        if (SLAB_AXIS >= 0) pre = slab_operands<SLAB_AXIS < 0 ? 0 : SLAB_AXIS>(so, su, P.cmax, ((karg_f32_ptr)cf)[2 * 19]);
-        if (X_LDS) scan_regular<true, K_LDS, SLAB_AXIS>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
-        else scan_regular<true, K_LDS, SLAB_AXIS>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+        if (SLAB_AXIS >= 0) pre = slab_operands<SLAB_AXIS < 0 ? 0 : SLAB_AXIS>(so, su, KARG(cmax), ((karg_f32_ptr)cf)[2 * 19]);
+        if (X_LDS) scan_regular<true, K_LDS, SLAB_AXIS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+        else scan_regular<true, K_LDS, SLAB_AXIS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
         RTOW_STAMP(t_scan1);
       }
       // ---- the camera rays' hits: sky ends the path (binary64, raytracer.nim:18-20), a hit scatters
@@ -941,14 +951,14 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       bool sky = false, cont = false;
       f3 p = {0, 0, 0}, dn = {0, 0, 1};
       float ptr_ = 1.0f, ptg_ = 1.0f, ptb_ = 1.0f;
-      const bool struck = gen && pid >= 0 && RTOW_GUARDED(4, pid, P.n_list);
+      const bool struck = gen && pid >= 0 && RTOW_GUARDED(4, pid, KARG(n_list));
       f3 ball;
       float ball_l2;
       bool wants_ball = false;   // Lambertian and Metal scatter through randomInUnitSphere (hitrecord.nim:84,97)
-      if (struck) wants_ball = P.shade[pid].kind != kDielectric;
+      if (struck) wants_ball = KARG(shade)[pid].kind != kDielectric;
       unit_ball_wave(wants_ball, g2, ball, ball_l2, lane, (uint2*)cand.list RTOW_PROF_ARG);
       if (gen) {
-        if (P.hit_id && sample + P.sample_base == 0u && RTOW_GUARDED(3, pix2, (long long)P.n_rows * P.W)) P.hit_id[pix2] = pid;
+        if (KARG(hit_id) && sample + KARG(sample_base) == 0u && RTOW_GUARDED(3, pix2, (long long)KARG(n_rows) * P.W)) KARG(hit_id)[pix2] = pid;
         if (!struck) {
           // unitVector(r.dir).y = dir.y / length(dir); t = 0.5 (y + 1); (1 - t) * 1 + t * colour
           const double uy = dy / sqrt(dx * dx + dy * dy + dz * dz);
@@ -964,13 +974,13 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           f3 su;
           float tmin_unused;
           segment_begin(sd, su, tmin_unused);
-          const SphereShade sh = P.shade[pid];
-          cont = shade_at_ball(sh, p, su, g2, ball, ball_l2, dn, ptr_, ptg_, ptb_) && P.max_depth > 1;
+          const SphereShade sh = KARG(shade)[pid];
+          cont = shade_at_ball(sh, p, su, g2, ball, ball_l2, dn, ptr_, ptg_, ptb_) && KARG(max_depth) > 1;
         }
       }
       RTOW_COUNT(21, __popcll(__ballot(sky)));
       RTOW_COUNT(22, __popcll(__ballot(gen && !sky)));
-      flush_sums(P.accum, sums, sky, pix2, fr, fg, fb, lane);
+      flush_sums(sums, sky, pix2, fr, fg, fb, lane);
       const uint64_t m = __ballot(cont);
       if (cont) {
         const uint32_t slot = lanes_below(m);
@@ -996,8 +1006,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         int id = -1;
         if (alive) {
           segment_begin(d, u, tmin);
-          for (int k = 0; k < P.n_big; ++k) {
-            const BigSphere bs = P.big[k];
+          for (int k = 0; k < KARG(n_big); ++k) {
+            const BigSphere bs = KARG(big)[k];
             float t;
             const bool ok = big_candidate(o, u, bs, tmin, bs.index == prev, t);
             offer(ok, t, bs.index, best, id);
@@ -1010,9 +1020,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       RTOW_STAMP(t_scan0);
       // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
       if (X_LDS && exhausted && (uint32_t)__popcll(__ballot(alive)) <= kSparseLanes)
-        scan_sparse(exact_lds, nk_lds, cand, P.n_geom_pad, P.cmax, alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
-      else if (X_LDS) scan_regular<false, K_LDS, -1>(geom, exact_lds, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
-      else scan_regular<false, K_LDS, -1>(geom, (const f4v*)P.geom_exact, nk_lds, cand, P.n_geom_pad / 4, P.cmax, alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
+        scan_sparse(exact_lds, nk_lds, cand, KARG(n_geom_pad), KARG(cmax), alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      else if (X_LDS) scan_regular<false, K_LDS, -1>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
+      else scan_regular<false, K_LDS, -1>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
       RTOW_STAMP(t_scan1);
       // A path that ends adds its radiance to its pixel right away, through the wave's cache of pixel sums
       // (paths that end absorbed or at the depth limit are black and add nothing).
@@ -1021,11 +1031,11 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       const unsigned long long key = cand.best[lane];
       const float best = __uint_as_float((uint32_t)(key >> 32));
       const int id = hit_key_id(key);
-      const bool struck = alive && id >= 0 && RTOW_GUARDED(5, id, P.n_list);
+      const bool struck = alive && id >= 0 && RTOW_GUARDED(5, id, KARG(n_list));
       f3 ball;
       float ball_l2;
       bool wants_ball = false;   // Lambertian and Metal scatter through randomInUnitSphere (hitrecord.nim:84,97)
-      if (struck) wants_ball = P.shade[id].kind != kDielectric;
+      if (struck) wants_ball = KARG(shade)[id].kind != kDielectric;
       unit_ball_wave(wants_ball, g, ball, ball_l2, lane, (uint2*)cand.list RTOW_PROF_ARG);
       if (alive) {
         float rr_ = 0.0f, rg_ = 0.0f, rb_ = 0.0f;
@@ -1037,7 +1047,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           shade_kind = -1;
 #endif
         } else {
-          const SphereShade sh = P.shade[id];
+          const SphereShade sh = KARG(shade)[id];
           f3 dn;
           const f3 p = {fmaf(best, u.x, o.x), fmaf(best, u.y, o.y), fmaf(best, u.z, o.z)};
           o = p;   // the scattered ray starts at the hit point whether or not it survives
@@ -1055,7 +1065,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           alive = false;
         }
       }
-      flush_sums(P.accum, sums, (fr | fg | fb) != 0u, pix, widen_fix(fr), widen_fix(fg), widen_fix(fb), lane);
+      flush_sums(sums, (fr | fg | fb) != 0u, pix, widen_fix(fr), widen_fix(fg), widen_fix(fb), lane);
     }
     RTOW_COUNT(3, 1);
 #ifdef RTOW_PROFILE_COUNTERS
@@ -1087,7 +1097,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 #ifdef RTOW_PROFILE_TIMELINE
   if (lane == 0 && wave_id < 16384) g_wave_times[12 * wave_id + 10] = __builtin_amdgcn_s_memrealtime();
 #endif
-  sum_cache_drain(P.accum, sums, lane);
+  sum_cache_drain(sums, lane);
   RTOW_PROF_FLUSH();
 #ifdef RTOW_PROFILE_TIMELINE
   if (lane == 0 && wave_id < 16384) {
@@ -1097,10 +1107,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 #endif
   // ray-segment count: wave reduction, one atomic per wave
   const unsigned long long total = nseg_bounce + nseg_primary;
-  if (lane == 0) atomicAdd(P.seg_counter, total);
+  if (lane == 0) atomicAdd(KARG(seg_counter), total);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    P.seg_counter[4] = __builtin_amdgcn_s_memtime();
-    P.seg_counter[5] = __builtin_amdgcn_s_memrealtime();
+    KARG(seg_counter)[4] = __builtin_amdgcn_s_memtime();
+    KARG(seg_counter)[5] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -14,6 +14,8 @@ a = ap.parse_args()
 scene = {"C2": lambda: R.randomScene(), "C3": lambda: R.randomScene(lambertBelow=0.0, metalBelow=0.5),
          "C5": lambda: R.randomScene(halfExtent=50)}[a.workload]()
 n = len(scene)
+scene = scene.flatten()
+scene.pop("hittable_kind")   # builds from before rtow_set_hittables take the plain sphere arrays
 rows = None if a.share == 1 else multigpu.tile_rows(800, a.share, 0, 4)
 rs = []
 for path in a.libs:
