@@ -198,10 +198,9 @@ static void release_scratch(rtow_ctx* c) {
 // one being filled by the copy engine while the host empties the other - run at PCIe rate.
 constexpr size_t kStagingBytes = 8u << 20;
 static int copy_to_host(rtow_ctx* c, void* dst, const void* src_dev, size_t bytes) {
-  if (bytes < 2 * kStagingBytes) {
-    HIP_TRY(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
-    return RTOW_OK;
-  }
+  // Every copy, small ones included, runs on the context's own stream through the context's own pinned buffers:
+  // a blocking hipMemcpy would go through the NULL stream and the runtime's shared staging memory, which the
+  // context's (non-blocking) stream is not ordered against and which all host threads of the process share.
   for (int k = 0; k < 2; ++k) {
     if (!c->staging[k]) HIP_TRY(hipHostMalloc((void**)&c->staging[k], kStagingBytes, hipHostMallocDefault));
     if (!c->staging_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->staging_ev[k], hipEventDisableTiming));
@@ -364,8 +363,8 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   const int n_pad = ((n + rtow::kGeomPad - 1) / rtow::kGeomPad) * rtow::kGeomPad;
   // four spheres per 16-float group: cx0 cx1 cy0 cy1 cz0 cz1 | cx2 cx3 cy2 cy3 cz2 cz3 | k0 k1 k2 k3
   // with k = |c|^2 - r^2 (+inf: never passes the filter)
-  // plus one all-padding group behind the last one (the scan prefetches past the end)
-  const int n_alloc = n_pad + 4;
+  // plus two all-padding groups behind the last one (the scan prefetches up to three groups ahead)
+  const int n_alloc = n_pad + 8;
   std::vector<float> geom((size_t)n_alloc * 4, 0.0f);
   auto geom_at = [&geom](int j, int field) -> float& {
     if (field == 3) return geom[(size_t)(j / 4) * 16 + 12 + (size_t)(j % 4)];
@@ -418,22 +417,25 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
     }
   }
   HIP_TRY(c->geom64.reserve(sizeof(double4) * geom64.size()));
-  HIP_TRY(hipMemcpy(c->geom64.p, geom64.data(), sizeof(double4) * geom64.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(c->geom64.p, geom64.data(), sizeof(double4) * geom64.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
   HIP_TRY(c->geom_slab.reserve(sizeof(float) * slab.size()));
-  HIP_TRY(hipMemcpy(c->geom_slab.p, slab.data(), sizeof(float) * slab.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(c->geom_slab.p, slab.data(), sizeof(float) * slab.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
   HIP_TRY(c->big.reserve(sizeof(rtow::BigSphere) * (big.empty() ? 1 : big.size())));
-  HIP_TRY(hipMemcpy(c->geom.p, geom.data(), sizeof(float) * geom.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->geom_rr.p, exact.data(), sizeof(float4) * exact.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->geom_nk.p, nk.data(), sizeof(float) * nk.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(c->geom.p, geom.data(), sizeof(float) * geom.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->geom_rr.p, exact.data(), sizeof(float4) * exact.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->geom_nk.p, nk.data(), sizeof(float) * nk.size(), hipMemcpyHostToDevice, c->stream));
   c->cmax = cmax;
   c->rmax = rmax;
-  HIP_TRY(hipMemcpy(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice, c->stream));
   if (!big.empty())
-    HIP_TRY(hipMemcpy(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice, c->stream));
+  // The uploads are ordered on the context's stream, like the renders that read the tables; the staging vectors
+  // above must outlive the copies.
+  HIP_TRY(hipStreamSynchronize(c->stream));
   c->n_spheres = n; c->n_geom_pad = n_pad; c->n_big = (int)big.size();
   c->blocks_per_cu = rtow::trace_blocks_per_cu(n_pad);
   if (const char* cap = getenv("RTOW_BLOCKS_PER_CU")) {  // experiments only: cap the resident workgroups per CU
@@ -908,10 +910,10 @@ static int render_multi_impl(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int
     const std::vector<int32_t>& r = plan.rows[(size_t)k];
     if (rc == RTOW_OK && rgb_out && !r.empty()) {
       staging.resize(row_bytes * r.size());
-      hipError_t e = hipSetDevice(c->device);
-      if (e == hipSuccess) e = hipMemcpy(staging.data(), c->rgb.p, staging.size(), hipMemcpyDeviceToHost);
+      const hipError_t e = hipSetDevice(c->device);
       if (e != hipSuccess) rc = fail(RTOW_ERR_DEVICE, "rtow_render_multi: %s", hipGetErrorString(e));
-      else
+      else rc = copy_to_host(c, staging.data(), c->rgb.p, staging.size());
+      if (rc == RTOW_OK)
         for (size_t i = 0; i < r.size(); ++i)
           memcpy(rgb_out + row_bytes * (size_t)r[i], staging.data() + row_bytes * i, row_bytes);
     }

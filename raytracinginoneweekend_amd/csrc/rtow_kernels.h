@@ -17,9 +17,9 @@ struct TraceParams {
   CameraParams64 cam;        // must stay first: the kernel reads it straight from its argument segment
   float rmax;                // largest |radius| in the binary32 table (scales the slab test's slack)
   float pad_;
-  const float* geom;         // n_geom_pad/4 groups of 16 floats (layout: scan_regular), list order; the last four of a group
+  const float* geom;         // n_geom_pad/4 + 2 groups of 16 floats (layout: scan_regular), list order; the last four of a group
                              // are k for tables beyond kMaxSpheresKInLds entries, -r^2 (slab test) for the others
-  const float* geom_nk;      // -k per list entry (n_geom_pad + 4 values): copied to LDS by each workgroup
+  const float* geom_nk;      // -k per list entry (n_geom_pad + 8 values): copied to LDS by each workgroup
   const float4* geom_exact;  // (cx, cy, cz, r^2) per list entry, fetched per lane for the exact test
   const double4* geom64;     // (cx, cy, cz, r) per list entry in binary64: the exact test of primary rays
   const float* geom_slab;    // -r^2 per table entry (+inf: never passes) for tables beyond kMaxSpheresKInLds entries

@@ -485,8 +485,8 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, f4v nk, nk
   }
 }
 
-// n_groups is even and the table holds one more (all-padding) group after the last one, so the
-// loop can always request two groups ahead without a bounds test.
+// n_groups is even and the table holds two more (all-padding) groups after the last one, so the
+// loop can always request up to three groups ahead without a bounds test.
 //
 // K_LDS: -k of every sphere sits in LDS (copied once per workgroup) and reaches the filter as a
 // VGPR pair through a broadcast ds_read_b128 issued one group ahead.  That lets the second chain
@@ -517,6 +517,51 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   constexpr bool NK_LATE = SLAB && K_LDS;
   f4v ka = (K_LDS && !NK_LATE) ? nk[0] : f4v{0, 0, 0, 0}, kb = ka;
   GroupRec ga = load_group<K_LDS, SLAB>(geom, 0, ka, slab);
+#ifndef RTOW_NO_PAIRED_GROUPS
+  if (!SLAB) {
+    // Scans without the slab test decide about EIGHT spheres with one compare and one branch: both groups of a
+    // trip are screened, then the largest of the eight values is compared with the threshold (three v_max3 and a
+    // v_max instead of twice v_max + v_max3, and one v_cmp instead of two: 33 instead of 34 instructions per
+    // eight spheres).  A group's scalar registers are free as soon as its fourteen FMAs are done, so the next
+    // group is requested right behind them, as before.
+    GroupRec gb = load_group<K_LDS, SLAB>(geom, 1, kb, slab);
+    if (K_LDS) kb = nk[1];
+    for (int g = 0; g < n_groups; g += 2) {
+      const f2v a0 = pair_filter(ga.a.s01, ga.a.s23, ga.a.s45, ka.xy, r);
+      const f2v a1 = pair_filter(ga.a.s67, ga.b.xy, ga.b.zw, ka.zw, r);
+      ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
+      if (K_LDS) ka = nk[2];
+      const f2v b0 = pair_filter(gb.a.s01, gb.a.s23, gb.a.s45, kb.xy, r);
+      const f2v b1 = pair_filter(gb.a.s67, gb.b.xy, gb.b.zw, kb.zw, r);
+      // the next -k may only be requested once this one has been consumed: hoisted above the last FMA it would need
+      // registers of its own, and the loop would begin by copying four registers
+      __builtin_amdgcn_sched_barrier(0);
+      gb = load_group<K_LDS, SLAB>(geom, g + 3, kb, slab);
+      if (K_LDS) kb = nk[3];
+      const float ma = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
+      const float mx = fmaxf(fmaxf(b0.x, b0.y), fmaxf(fmaxf(b1.x, b1.y), ma));
+      if (__ballot(mx >= r.ozt.y) != 0) {   // wave-uniform: the list's fill count stays a scalar
+        RTOW_COUNT(9, 1);
+        const int j = 4 * g;
+        if (__ballot(ma >= r.ozt.y) != 0) {
+          cand_push(cand, a0.x >= r.ozt.y, j);
+          cand_push(cand, a0.y >= r.ozt.y, j + 1);
+          cand_push(cand, a1.x >= r.ozt.y, j + 2);
+          cand_push(cand, a1.y >= r.ozt.y, j + 3);
+          if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+        }
+        cand_push(cand, b0.x >= r.ozt.y, j + 4);
+        cand_push(cand, b0.y >= r.ozt.y, j + 5);
+        cand_push(cand, b1.x >= r.ozt.y, j + 6);
+        cand_push(cand, b1.y >= r.ozt.y, j + 7);
+        if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      }
+      if (K_LDS) nk += 2;
+    }
+    cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    return;
+  }
+#endif
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
     if (K_LDS && !NK_LATE) kb = nk[1];
@@ -708,7 +753,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
 #endif
   }
   if (K_LDS) {
-    const int n4 = P.n_geom_pad / 4 + 1;
+    const int n4 = P.n_geom_pad / 4 + 2;
     f4v* const dst = lds_raw + (kTraceThreads / 64) * L::kTotal / 4;
     for (int i = threadIdx.x; i < n4; i += kTraceThreads) dst[i] = ((const f4v*)P.geom_nk)[i];
     if (X_LDS) {
@@ -718,7 +763,7 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     __syncthreads();
   }
   typedef const f4v __attribute__((address_space(3)))* exact_lds_ptr;
-  const exact_lds_ptr exact_lds = (exact_lds_ptr)(nk_lds + (P.n_geom_pad / 4 + 1));
+  const exact_lds_ptr exact_lds = (exact_lds_ptr)(nk_lds + (P.n_geom_pad / 4 + 2));
 
   // wave-uniform: the chunk being handed out.  A chunk is a run of consecutive paths in
   // pixel-major order (all samples of a pixel, then the next pixel of the row list).
@@ -1124,9 +1169,9 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
 static size_t wave_lds_bytes(bool short_entries) {
   return sizeof(uint32_t) * (kTraceThreads / 64) * (short_entries ? WaveLds<true>::kTotal : WaveLds<false>::kTotal);
 }
-static size_t k_lds_bytes(int n_geom_pad) { return wave_lds_bytes(false) + sizeof(float) * (size_t)(n_geom_pad + 4); }
+static size_t k_lds_bytes(int n_geom_pad) { return wave_lds_bytes(false) + sizeof(float) * (size_t)(n_geom_pad + 8); }
 static size_t kx_lds_bytes(int n_geom_pad) {
-  return wave_lds_bytes(true) + sizeof(float) * (size_t)(n_geom_pad + 4) + sizeof(float4) * (size_t)n_geom_pad;
+  return wave_lds_bytes(true) + sizeof(float) * (size_t)(n_geom_pad + 8) + sizeof(float4) * (size_t)n_geom_pad;
 }
 
 template <int SLAB_AXIS>

@@ -888,7 +888,12 @@ def test_one_context_per_thread_renders_concurrently(gpu_renderer):
         t.join()
     assert not errors, errors
     for k in range(len(jobs)):
-        assert (got[k] == alone[k]).all(), f"job {k}"
+        if not (got[k] == alone[k]).all():   # say which side is off before failing
+            again = gpu_renderer.renderRows(W, H, jobs[k][0], jobs[k][1], want_accum=True)[1]
+            differing = np.argwhere((got[k] != alone[k]).any(axis=2))
+            pytest.fail(f"job {k}: {len(differing)} pixels differ, first at {differing[:3].tolist()}; a second lone render "
+                        f"equals the first lone one: {bool((again == alone[k]).all())}, equals the threaded one: "
+                        f"{bool((again == got[k]).all())}")
 
 
 def test_progressive_passes_reach_the_single_render_image(gpu_renderer):
