@@ -8,9 +8,12 @@ depth 50, 484 spheres, seed 0xE7): clear + trace + resolve on the GPU with scene
 already resident; nothing crosses PCIe inside the timed region except the 16-byte counter
 read-back.  Steps are kept two deep in flight (two contexts, each with its own stream and
 buffers, used in turn): the tail of a frame overlaps the start of the next one.  All K steps
-start and complete inside the timed region; `latency_ms_per_step` is one step on its own.  With N > 1 (launched by torch.distributed.run, one process per GPU) the same frame
-is sharded by interleaved row tiles and each step ends with the RCCL gather of the 8-bit rows,
-so total work is fixed ("strong" scaling).
+start and complete inside the timed region; `latency_ms_per_step` is one step on its own.
+With N > 1 - one process per GPU: either started by torch.distributed.run, or by this script
+itself when it is called plainly as `python bench.py --gpus N` (it then starts the N workers
+before touching any GPU and relays rank 0's line) - the same frame is sharded by interleaved
+row tiles and each step ends with the RCCL gather of the 8-bit rows, so total work is fixed
+("strong" scaling).
 
 Prints ONE JSON line on rank 0.  value = ray segments (world.hit queries) of all ranks / wall
 seconds / 1e6.  roofline: algorithmic FLOP (18 per ray-sphere test, 18*N+65 per segment) over
@@ -32,8 +35,8 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256
 FLOP_PER_TEST = 18             # hitrecord.nim:56-61: oc 3, half_b 5, |oc|^2 5, r*r 1, c 1, disc 3
 FLOP_PER_SEGMENT_EXTRA = 65    # a = |dir|^2 once, hit epilogue, scatter, sky (amortised)
 FLOP_PER_TEST_EXECUTED = 14    # what the kernel's screen really issues per sphere: 7 packed FMAs per pair
-FLOP_PER_SLAB_TEST = 6         # camera rays (one pixel's samples per wave) see a 3-FMA slab test first; about one group of four
-SLAB_PASS_FRACTION = 0.09      # spheres in eleven then goes on to the screen (profiles/: instrumented build, book scene)
+FLOP_PER_SLAB_TEST = 6         # camera rays (one pixel's samples per wave) see a 3-FMA slab test first; the groups of four
+                               # spheres that pass it in some lane go on to the screen: slab_pass_fraction() below
 
 WORKLOADS = {
     # name: (width, height, spp, depth, half_extent, lambert_below, metal_below)
@@ -41,6 +44,17 @@ WORKLOADS = {
     "C3": (1200, 800, 500, 50, 11, 0.0, 0.5),     # every small sphere metal or glass
     "C5": (3840, 2160, 1024, 50, 50, 0.8, 0.95),  # ~10k spheres, brute force
 }
+
+
+def slab_pass_fraction(workload, spp):
+    """Share of a PRIMARY scan's groups that go on from the slab test to the screen, measured per workload with the
+    instrumented build (profiles/r*_slab_pass_fraction.json).  None for a configuration it was not measured on
+    (another sample count changes which rays share a wavefront)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_slab_pass_fraction.json")))
+    if not found or spp != WORKLOADS[workload][2]:
+        return None
+    return json.load(open(found[-1])).get(workload)
 
 
 def hbm_traffic(workload, spp, world):
@@ -296,6 +310,13 @@ def main():
         avg_trace_s = sum(trace_ms) / len(trace_ms) * 1e-3
         achieved = serial[-1]["ray_segments"] * flop_per_segment / avg_trace_s / 1e12
         paths = width * height * spp
+        pass_fraction = slab_pass_fraction(args.workload, spp) if slab_used else 0.0
+        if pass_fraction is None:
+            executed = None
+        else:
+            executed = ((serial[-1]["ray_segments"] - (serial[-1]["paths"] if slab_used else 0)) * FLOP_PER_TEST_EXECUTED
+                        + (serial[-1]["paths"] * (FLOP_PER_SLAB_TEST + pass_fraction * FLOP_PER_TEST_EXECUTED) if slab_used else 0)
+                        ) * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS
         out = {
             "metric": "Mrays/sec (ray segments = world.hit queries) book-1 final scene 1200x800 spp500 depth50"
                       + ("" if args.workload == "C2" and not args.spp else f" -- NOT the headline configuration: see config.workload"),
@@ -339,10 +360,8 @@ def main():
                 # kernel screens every sphere with 14 FLOP (7 packed FMAs per pair) and runs the full test on
                 # the ~1.2 survivors per ray, so the share of the VALU peak it really issues is lower:
                 # (camera-ray segments - one per path - see the 6-FLOP slab test and the screen for the groups that pass it)
-                "frac_executed_screen_only": (
-                    (serial[-1]["ray_segments"] - (serial[-1]["paths"] if slab_used else 0)) * FLOP_PER_TEST_EXECUTED
-                    + (serial[-1]["paths"] * (FLOP_PER_SLAB_TEST + SLAB_PASS_FRACTION * FLOP_PER_TEST_EXECUTED) if slab_used else 0)
-                ) * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                "frac_executed_screen_only": executed,
+                "slab_pass_fraction": pass_fraction if slab_used else None,
                 "note": "achieved = ray segments x the reference's 18 FLOP per ray-sphere pair (+65 per segment); the kernel decides "
                         "most pairs with fewer operations (3 FMAs for camera rays, 7 otherwise: frac_executed_screen_only), so frac "
                         "measures work delivered against the VALU peak and can approach or exceed 1 on long sphere lists",

@@ -117,6 +117,32 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, int iters, unsign
             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
             : "s"(sp), "v"(c));
       }
+    } else if (MODE == 10) {
+      // SGPR source read as ONE dword for both halves (op_sel / op_sel_hi both 0 on src0)
+      const f2 sp = {__builtin_amdgcn_readfirstlane(i) * 1e-9f + 0.999f, 0.998f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile(
+            "v_pk_fma_f32 %0, %8, %0, %9 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %1, %8, %1, %9 op_sel_hi:[0,1,1]\n"
+            "v_pk_fma_f32 %2, %8, %2, %9 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %3, %8, %3, %9 op_sel_hi:[0,1,1]\n"
+            "v_pk_fma_f32 %4, %8, %4, %9 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %5, %8, %5, %9 op_sel_hi:[0,1,1]\n"
+            "v_pk_fma_f32 %6, %8, %6, %9 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %7, %8, %7, %9 op_sel_hi:[0,1,1]\n"
+            : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+            : "s"(sp), "v"(cc));
+      }
+    } else if (MODE == 11) {
+      // SGPR pair source, the two VGPR sources the SAME register pair (fewer VGPR reads per instruction)
+      const f2 sp = {__builtin_amdgcn_readfirstlane(i) * 1e-9f + 0.999f, 0.998f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        asm volatile(
+            "v_pk_fma_f32 %0, %8, %0, %0\n v_pk_fma_f32 %1, %8, %1, %1\n"
+            "v_pk_fma_f32 %2, %8, %2, %2\n v_pk_fma_f32 %3, %8, %3, %3\n"
+            "v_pk_fma_f32 %4, %8, %4, %4\n v_pk_fma_f32 %5, %8, %5, %5\n"
+            "v_pk_fma_f32 %6, %8, %6, %6\n v_pk_fma_f32 %7, %8, %7, %7\n"
+            : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+            : "s"(sp), "v"(cc));
+      }
     } else if (MODE == 5) {
       // v_pk_mul_f32 / v_pk_add_f32 mix
 #pragma unroll
@@ -317,6 +343,8 @@ static void launch_rate(void* p) {
     case 7: hipLaunchKernelGGL(rate_kernel<7>, g, b, 0, 0, c->out, c->iters, c->clk); break;
     case 8: hipLaunchKernelGGL(rate_kernel<8>, g, b, 0, 0, c->out, c->iters, c->clk); break;
     case 9: hipLaunchKernelGGL(rate_kernel<9>, g, b, 0, 0, c->out, c->iters, c->clk); break;
+    case 10: hipLaunchKernelGGL(rate_kernel<10>, g, b, 0, 0, c->out, c->iters, c->clk); break;
+    case 11: hipLaunchKernelGGL(rate_kernel<11>, g, b, 0, 0, c->out, c->iters, c->clk); break;
   }
 }
 
@@ -344,15 +372,15 @@ int main() {
   // (1) raw rates
   float* d_out; CK(hipMalloc(&d_out, sizeof(float) * 256 * CU * 8));
   unsigned long long* d_clk; CK(hipMalloc(&d_clk, 16));
-  const char* rn[] = {"v_fma_f32(vop3)", "v_pk_fma_f32", "v_fmac_f32(vop2)", "test-body(11)", "v_pk_fma(sgpr src)", "v_pk_mul/add", "v_mul_lo_u32", "v_pk_fma(sgpr src1)", "v_pk_fma(sgpr src2)", "v_fma_f32(sgpr src)"};
-  for (int mode = 0; mode < 10; ++mode)
+  const char* rn[] = {"v_fma_f32(vop3)", "v_pk_fma_f32", "v_fmac_f32(vop2)", "test-body(11)", "v_pk_fma(sgpr src)", "v_pk_mul/add", "v_mul_lo_u32", "v_pk_fma(sgpr src1)", "v_pk_fma(sgpr src2)", "v_fma_f32(sgpr src)", "v_pk_fma(sgpr dword)", "v_pk_fma(sgpr,2 vgpr)"};
+  for (int mode = 0; mode < 12; ++mode)
     for (int wps = 1; wps <= 8; wps *= 2) {
       RateCtx c{d_out, 40000, CU * wps, 256, mode, d_clk};
       double s = run_timed(launch_rate, &c, 3);
       unsigned long long hclk[2]; CK(hipMemcpy(hclk, d_clk, 16, hipMemcpyDeviceToHost));
       double per = (mode == 3 ? 33 : 32);
       double instr = (double)c.blocks * 256 * c.iters * per;  // lane-instructions
-      double flops = instr * 2 * ((mode == 1 || mode == 4 || mode == 7 || mode == 8) ? 2 : 1);
+      double flops = instr * 2 * ((mode == 1 || mode == 4 || mode == 7 || mode == 8 || mode == 10 || mode == 11) ? 2 : 1);
       printf("rate %-17s waves/SIMD %d : %.3f ms  %.1f Glane-instr/s  %.1f TFLOP/s  | %.2f cyc/instr/wave  clk %.0f MHz\n",
              rn[mode], wps, s * 1e3, instr / s * 1e-9, flops / s * 1e-12,
              (double)hclk[0] / (c.iters * per), (double)hclk[0] / (double)hclk[1] * 100.0);
