@@ -485,6 +485,46 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, f4v nk, nk
   }
 }
 
+// One trip of a scan without the slab test: the two groups g and g + 1 (in ga / gb, their -k in ka / kb) are screened
+// and the largest of the eight values is compared with the threshold - three v_max3 and a v_max instead of twice
+// v_max + v_max3, one v_cmp instead of two: 33 instead of 34 instructions per eight spheres.  A group's scalar
+// registers are free as soon as its fourteen FMAs are done, so groups g + 2 and g + 3 are requested right behind
+// them.  nk points at -k of group g - OFF (OFF is a compile-time offset, so the reads use immediate offsets).
+template <bool PRIMARY, bool K_LDS, int OFF, bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void pair_step(geom_ptr geom, int g, nk_lds_ptr nk, GroupRec& ga, GroupRec& gb, f4v& ka,
+                                                 f4v& kb, ExactPtr exact, CandList<SHORT>& cand, const ScanRay& r, f3 o, f3 u,
+                                                 float tmin, int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
+  const f2v a0 = pair_filter(ga.a.s01, ga.a.s23, ga.a.s45, ka.xy, r);
+  const f2v a1 = pair_filter(ga.a.s67, ga.b.xy, ga.b.zw, ka.zw, r);
+  ga = load_group<K_LDS, false>(geom, g + 2, ka, nullptr);
+  if (K_LDS) ka = nk[OFF + 2];
+  const f2v b0 = pair_filter(gb.a.s01, gb.a.s23, gb.a.s45, kb.xy, r);
+  const f2v b1 = pair_filter(gb.a.s67, gb.b.xy, gb.b.zw, kb.zw, r);
+  // the next -k may only be requested once this one has been consumed: hoisted above the last FMA it would need
+  // registers of its own, and the trip would begin by copying four registers
+  __builtin_amdgcn_sched_barrier(0);
+  gb = load_group<K_LDS, false>(geom, g + 3, kb, nullptr);
+  if (K_LDS) kb = nk[OFF + 3];
+  const float ma = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
+  const float mx = fmaxf(fmaxf(b0.x, b0.y), fmaxf(fmaxf(b1.x, b1.y), ma));
+  if (__ballot(mx >= r.ozt.y) != 0) {   // wave-uniform: the list's fill count stays a scalar
+    RTOW_COUNT(9, 1);
+    const int j = 4 * g;
+    if (__ballot(ma >= r.ozt.y) != 0) {
+      cand_push(cand, a0.x >= r.ozt.y, j);
+      cand_push(cand, a0.y >= r.ozt.y, j + 1);
+      cand_push(cand, a1.x >= r.ozt.y, j + 2);
+      cand_push(cand, a1.y >= r.ozt.y, j + 3);
+      if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    }
+    cand_push(cand, b0.x >= r.ozt.y, j + 4);
+    cand_push(cand, b0.y >= r.ozt.y, j + 5);
+    cand_push(cand, b1.x >= r.ozt.y, j + 6);
+    cand_push(cand, b1.y >= r.ozt.y, j + 7);
+    if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+  }
+}
+
 // n_groups is even and the table holds two more (all-padding) groups after the last one, so the
 // loop can always request up to three groups ahead without a bounds test.
 //
@@ -519,57 +559,38 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   GroupRec ga = load_group<K_LDS, SLAB>(geom, 0, ka, slab);
 #ifndef RTOW_NO_PAIRED_GROUPS
   if (!SLAB) {
-    // Scans without the slab test decide about EIGHT spheres with one compare and one branch: both groups of a
-    // trip are screened, then the largest of the eight values is compared with the threshold (three v_max3 and a
-    // v_max instead of twice v_max + v_max3, and one v_cmp instead of two: 33 instead of 34 instructions per
-    // eight spheres).  A group's scalar registers are free as soon as its fourteen FMAs are done, so the next
-    // group is requested right behind them, as before.
+    // Scans without the slab test decide about EIGHT spheres with one compare and one branch (pair_step), and the
+    // loop is unrolled four pairs deep so that -k of all eight groups is read through immediate offsets from one
+    // address register: the address advances once per 32 spheres instead of once per eight.
     GroupRec gb = load_group<K_LDS, SLAB>(geom, 1, kb, slab);
     if (K_LDS) kb = nk[1];
-    for (int g = 0; g < n_groups; g += 2) {
-      const f2v a0 = pair_filter(ga.a.s01, ga.a.s23, ga.a.s45, ka.xy, r);
-      const f2v a1 = pair_filter(ga.a.s67, ga.b.xy, ga.b.zw, ka.zw, r);
-      ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
-      if (K_LDS) ka = nk[2];
-      const f2v b0 = pair_filter(gb.a.s01, gb.a.s23, gb.a.s45, kb.xy, r);
-      const f2v b1 = pair_filter(gb.a.s67, gb.b.xy, gb.b.zw, kb.zw, r);
-      // the next -k may only be requested once this one has been consumed: hoisted above the last FMA it would need
-      // registers of its own, and the loop would begin by copying four registers
-      __builtin_amdgcn_sched_barrier(0);
-      gb = load_group<K_LDS, SLAB>(geom, g + 3, kb, slab);
-      if (K_LDS) kb = nk[3];
-      const float ma = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
-      const float mx = fmaxf(fmaxf(b0.x, b0.y), fmaxf(fmaxf(b1.x, b1.y), ma));
-      if (__ballot(mx >= r.ozt.y) != 0) {   // wave-uniform: the list's fill count stays a scalar
-        RTOW_COUNT(9, 1);
-        const int j = 4 * g;
-        if (__ballot(ma >= r.ozt.y) != 0) {
-          cand_push(cand, a0.x >= r.ozt.y, j);
-          cand_push(cand, a0.y >= r.ozt.y, j + 1);
-          cand_push(cand, a1.x >= r.ozt.y, j + 2);
-          cand_push(cand, a1.y >= r.ozt.y, j + 3);
-          if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
-        }
-        cand_push(cand, b0.x >= r.ozt.y, j + 4);
-        cand_push(cand, b0.y >= r.ozt.y, j + 5);
-        cand_push(cand, b1.x >= r.ozt.y, j + 6);
-        cand_push(cand, b1.y >= r.ozt.y, j + 7);
-        if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
-      }
+    int g = 0;
+    for (; g + 8 <= n_groups; g += 8) {
+      pair_step<PRIMARY, K_LDS, 0>(geom, g, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      pair_step<PRIMARY, K_LDS, 2>(geom, g + 2, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      pair_step<PRIMARY, K_LDS, 4>(geom, g + 4, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      pair_step<PRIMARY, K_LDS, 6>(geom, g + 6, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      if (K_LDS) nk += 8;
+    }
+    for (; g < n_groups; g += 2) {
+      pair_step<PRIMARY, K_LDS, 0>(geom, g, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
       if (K_LDS) nk += 2;
     }
     cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
     return;
   }
 #endif
+  // (NK_LATE: the address of a group's -k is formed from the group index where it is needed - one group in eleven -
+  // instead of being carried along in a register that every trip has to advance)
+  const nk_lds_ptr nk_base = (nk_lds_ptr)nk_lds;
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
     if (K_LDS && !NK_LATE) kb = nk[1];
-    group_test<PRIMARY, AXIS, NK_LATE>(ga, ka, nk, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, AXIS, NK_LATE>(ga, ka, NK_LATE ? nk_base + g : nk, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
     ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
     if (K_LDS && !NK_LATE) ka = nk[2];
-    group_test<PRIMARY, AXIS, NK_LATE>(gb, kb, nk + 1, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
-    if (K_LDS) nk += 2;
+    group_test<PRIMARY, AXIS, NK_LATE>(gb, kb, NK_LATE ? nk_base + g + 1 : nk + 1, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    if (K_LDS && !NK_LATE) nk += 2;
   }
   cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
