@@ -975,10 +975,15 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         double closest = INFINITY;
         int pid = -1;
         for (int k = 0; k < KARG(n_big); ++k) {
-          const int j = KARG(big)[k].index;
+          // wave-uniform records, read with scalar loads (constant address space: no kernel writes these tables)
+          typedef const int32_t __attribute__((address_space(4)))* big_i32_ptr;
+          typedef const double __attribute__((address_space(4)))* geom_f64_ptr;
+          const int j = ((big_i32_ptr)(uintptr_t)KARG(big))[12 * k + 10];   // BigSphere::index
+          const geom_f64_ptr g64 = (geom_f64_ptr)(uintptr_t)KARG(geom64) + 4 * (size_t)(RTOW_GUARDED(2, j, KARG(n_list)) ? j : 0);
+          const double4 sp64 = make_double4(g64[0], g64[1], g64[2], g64[3]);
           double root;
           if (RTOW_GUARDED(2, j, KARG(n_list)) &&
-              sphere_hit_f64(o64[0], o64[1], o64[2], d64[0], d64[1], d64[2], a64, KARG(geom64)[j], root) && !(closest < root)) {
+              sphere_hit_f64(o64[0], o64[1], o64[2], d64[0], d64[1], d64[2], a64, sp64, root) && !(closest < root)) {
             closest = root;
             pid = j;
           }
@@ -1072,8 +1077,16 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         int id = -1;
         if (alive) {
           segment_begin(d, u, tmin);
+          // (read through the constant address space: wave-uniform scalar loads into SGPRs - the table is written by
+          // no kernel - instead of one vector load per lane from the same address)
+          typedef const double __attribute__((address_space(4)))* big_f64_ptr;
+          typedef const int32_t __attribute__((address_space(4)))* big_i32_ptr;
+          static_assert(sizeof(BigSphere) == 48 && offsetof(BigSphere, rr) == 32 && offsetof(BigSphere, index) == 40, "BigSphere layout");
+          const big_f64_ptr big = (big_f64_ptr)(uintptr_t)KARG(big);
           for (int k = 0; k < KARG(n_big); ++k) {
-            const BigSphere bs = KARG(big)[k];
+            BigSphere bs;
+            bs.cx = big[6 * k]; bs.cy = big[6 * k + 1]; bs.cz = big[6 * k + 2]; bs.r = big[6 * k + 3]; bs.rr = big[6 * k + 4];
+            bs.index = ((big_i32_ptr)(big + 6 * k + 5))[0]; bs.pad_ = 0;
             float t;
             const bool ok = big_candidate(o, u, bs, tmin, bs.index == prev, t);
             offer(ok, t, bs.index, best, id);
