@@ -195,11 +195,26 @@ static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
 // comes from LDS (scalar registers are the scarcest resource of this kernel), all 16 otherwise.  Spheres handled
 // elsewhere and the padding carry k = +inf, so they never pass.  r^2 for the exact test comes from
 // a separate array, fetched only when needed.
+// K_SGPR: -k sits in scalar registers (tables too large for the LDS copy).  A VALU instruction reads at most one
+// scalar operand, so -k cannot be the addend of an FMA whose multiplicand is a scalar centre coordinate; moved to
+// vector registers first it costs two instructions per pair of spheres.  It is added LAST instead - the second
+// chain starts as a product, n^2 + (2o).c is formed, and one packed add brings in -k: one instruction per pair.
+// The value differs from the other form's by rounding only (the terms have the same magnitudes), far inside the
+// margin; which spheres a screen lets through decides nothing but how many exact tests run.
+template <bool K_SGPR = false>
 static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, const f2v cz, const f2v nk,
                                                   const ScanRay& r) {
   f2v n = pk_fma_bcast<0, 2>(cx, r.uxy, r.uzn);   // cx * u.x - o.u
   n = pk_fma_bcast<1, 0>(cy, r.uxy, n);
   n = pk_fma_bcast<0, 0>(cz, r.uzn, n);
+  if (K_SGPR) {
+    f2v t, w;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "s"(cx), "v"(r.oxy));   // cx * 2o.x
+    t = pk_fma_bcast<1, 0>(cy, r.oxy, t);
+    t = pk_fma_bcast<0, 0>(cz, r.ozt, t);
+    w = __builtin_elementwise_fma(n, n, t) + nk;   // left to the compiler (a packed add with nk as its scalar operand):
+    return w;                                       // it then knows the sum is no signalling NaN and does not quiet it again
+  }
   f2v t = pk_fma_bcast<0, 0>(cx, r.oxy, nk);      // nk = -k, a VGPR pair (see K_LDS)
   t = pk_fma_bcast<1, 0>(cy, r.oxy, t);
   t = pk_fma_bcast<0, 0>(cz, r.ozt, t);
@@ -457,7 +472,7 @@ typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 
 // nk: -k of the four spheres, or (NK_LATE) nk_late points at them in LDS and they are fetched only if the group
 // gets as far as the filter
-template <bool PRIMARY, int AXIS, bool NK_LATE, bool SHORT, typename ExactPtr>
+template <bool PRIMARY, int AXIS, bool NK_LATE, bool K_SGPR, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void group_test(const GroupRec grp, f4v nk, nk_lds_ptr nk_late, int j, ExactPtr exact,
                                                   CandList<SHORT>& cand, const ScanRay& r, const f2v pre, f3 o, f3 u, float tmin,
                                                   int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
@@ -494,12 +509,12 @@ template <bool PRIMARY, bool K_LDS, int OFF, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void pair_step(geom_ptr geom, int g, nk_lds_ptr nk, GroupRec& ga, GroupRec& gb, f4v& ka,
                                                  f4v& kb, ExactPtr exact, CandList<SHORT>& cand, const ScanRay& r, f3 o, f3 u,
                                                  float tmin, int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
-  const f2v a0 = pair_filter(ga.a.s01, ga.a.s23, ga.a.s45, ka.xy, r);
-  const f2v a1 = pair_filter(ga.a.s67, ga.b.xy, ga.b.zw, ka.zw, r);
+  const f2v a0 = pair_filter<!K_LDS>(ga.a.s01, ga.a.s23, ga.a.s45, ka.xy, r);
+  const f2v a1 = pair_filter<!K_LDS>(ga.a.s67, ga.b.xy, ga.b.zw, ka.zw, r);
   ga = load_group<K_LDS, false>(geom, g + 2, ka, nullptr);
   if (K_LDS) ka = nk[OFF + 2];
-  const f2v b0 = pair_filter(gb.a.s01, gb.a.s23, gb.a.s45, kb.xy, r);
-  const f2v b1 = pair_filter(gb.a.s67, gb.b.xy, gb.b.zw, kb.zw, r);
+  const f2v b0 = pair_filter<!K_LDS>(gb.a.s01, gb.a.s23, gb.a.s45, kb.xy, r);
+  const f2v b1 = pair_filter<!K_LDS>(gb.a.s67, gb.b.xy, gb.b.zw, kb.zw, r);
   // the next -k may only be requested once this one has been consumed: hoisted above the last FMA it would need
   // registers of its own, and the trip would begin by copying four registers
   __builtin_amdgcn_sched_barrier(0);
@@ -586,10 +601,10 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
     if (K_LDS && !NK_LATE) kb = nk[1];
-    group_test<PRIMARY, AXIS, NK_LATE>(ga, ka, NK_LATE ? nk_base + g : nk, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(ga, ka, NK_LATE ? nk_base + g : nk, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
     ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
     if (K_LDS && !NK_LATE) ka = nk[2];
-    group_test<PRIMARY, AXIS, NK_LATE>(gb, kb, NK_LATE ? nk_base + g + 1 : nk + 1, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(gb, kb, NK_LATE ? nk_base + g + 1 : nk + 1, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
     if (K_LDS && !NK_LATE) nk += 2;
   }
   cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);

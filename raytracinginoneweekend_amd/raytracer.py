@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 from . import _lib, nimrandom
-from .basetypes import Color, Image, Point, Ray, Vec3, color, length, point, randomVec, vec3
+from .basetypes import Color, Image, Point, Ray, Vec3, color, length, point, vec3
 from .camera import Camera, initCamera
 from .hitrecord import (HitRecord, Sphere, initDielectric, initLambertian, initMaterial, initMetal)  # noqa: F401
 from .hittables import HittablesList, initHittables
@@ -405,39 +405,41 @@ def randomScene(halfExtent=11, lambertBelow=0.8, metalBelow=0.95, rng=None):
     the two material thresholds generalise it (a 101 x 101 grid, or an all metal/glass variant).
     Draws come from the Nim generator in its un-seeded state unless `rng` is given, because the
     reference builds the scene before it calls randomize (raytracer.nim:122 vs :135)."""
-    saved = nimrandom._global
-    nimrandom._global = rng if rng is not None else nimrandom.Rand()
-    try:
-        rand = nimrandom.rand
-        result = initHittables(0)
-        groundMaterial = initMaterial(initLambertian(color(0.5, 0.5, 0.5)))
-        result.add(Sphere(point(0, -1000, 0), 1000, groundMaterial))
-        for a in range(-halfExtent, halfExtent):
-            for b in range(-halfExtent, halfExtent):
-                chooseMat = rand(1.0)
-                cx = float(a) + 0.9 * rand(1.0)
-                cz = float(b) + 0.9 * rand(1.0)
-                center = point(cx, 0.2, cz)
-                if length(center - point(4, 0.2, 0)) > 0.9:
-                    if chooseMat < lambertBelow:
-                        first = randomVec()
-                        second = randomVec()
-                        albedo = Color(*(first * second))
-                        sphereMaterial = initMaterial(initLambertian(albedo))
-                    elif chooseMat < metalBelow:
-                        albedo = Color(*randomVec(0.5, 1.0))
-                        fuzz = rand(0.0, 0.5)
-                        sphereMaterial = initMaterial(initMetal(albedo, fuzz))
-                    else:
-                        sphereMaterial = initMaterial(initDielectric(1.5))
-                    result.add(Sphere(center, 0.2, sphereMaterial))
-        result.add(Sphere(point(0, 1, 0), 1.0, initMaterial(initDielectric(1.5))))
-        result.add(Sphere(point(-4, 1, 0), 1.0, initMaterial(initLambertian(color(0.4, 0.2, 0.1)))))
-        result.add(Sphere(point(4, 1, 0), 1.0, initMaterial(initMetal(color(0.7, 0.6, 0.5), 0.0))))
-        result.draws = nimrandom._global.draws
-        return result
-    finally:
-        nimrandom._global = saved
+    # A generator of this call's own: the module-level one (what the reference's rand() acts on) is neither touched
+    # nor shared, so scenes can be built from several host threads at once.
+    g = rng if rng is not None else nimrandom.Rand()
+    rand = g.rand
+
+    def randomVec(lo=0.0, hi=1.0):   # basetypes.nim:110-112 on this generator: x, y, z in this order
+        return Vec3(rand(lo, hi), rand(lo, hi), rand(lo, hi))
+
+    result = initHittables(0)
+    groundMaterial = initMaterial(initLambertian(color(0.5, 0.5, 0.5)))
+    result.add(Sphere(point(0, -1000, 0), 1000, groundMaterial))
+    for a in range(-halfExtent, halfExtent):
+        for b in range(-halfExtent, halfExtent):
+            chooseMat = rand(1.0)
+            cx = float(a) + 0.9 * rand(1.0)
+            cz = float(b) + 0.9 * rand(1.0)
+            center = point(cx, 0.2, cz)
+            if length(center - point(4, 0.2, 0)) > 0.9:
+                if chooseMat < lambertBelow:
+                    first = randomVec()
+                    second = randomVec()
+                    albedo = Color(*(first * second))
+                    sphereMaterial = initMaterial(initLambertian(albedo))
+                elif chooseMat < metalBelow:
+                    albedo = Color(*randomVec(0.5, 1.0))
+                    fuzz = rand(0.0, 0.5)
+                    sphereMaterial = initMaterial(initMetal(albedo, fuzz))
+                else:
+                    sphereMaterial = initMaterial(initDielectric(1.5))
+                result.add(Sphere(center, 0.2, sphereMaterial))
+    result.add(Sphere(point(0, 1, 0), 1.0, initMaterial(initDielectric(1.5))))
+    result.add(Sphere(point(-4, 1, 0), 1.0, initMaterial(initLambertian(color(0.4, 0.2, 0.1)))))
+    result.add(Sphere(point(4, 1, 0), 1.0, initMaterial(initMetal(color(0.7, 0.6, 0.5), 0.0))))
+    result.draws = g.draws
+    return result
 
 
 def bookCamera(aspectRatio):

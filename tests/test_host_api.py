@@ -84,6 +84,26 @@ def test_random_scene_host_equals_oracle(oracle):
     assert nimrandom.globalState().draws == 0
 
 
+def test_random_scene_from_several_threads_at_once():
+    """randomScene draws from a generator of its own: four host threads building the scene at the same time
+    (one context per thread is the library's threading model) all get the reference's 484 spheres."""
+    import threading
+    want = R.randomScene().flatten()
+    got = [None] * 4
+
+    def work(k):
+        for _ in range(3):
+            got[k] = R.randomScene().flatten()
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for g in got:
+        assert all((g[key] == want[key]).all() for key in want)
+
+
 def test_scene_variants():
     big = R.randomScene(halfExtent=14)
     assert 750 < len(big) <= 1 + 28 * 28 + 3
