@@ -542,12 +542,15 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   HIP_TRY(hipMemsetAsync(t.counters, 0, kCounterBytes, c->stream));
   if (first_sample == 0 && n_pixels) HIP_TRY(hipMemsetAsync(t.accum, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  // Camera rays see a slab test along one axis before the filter (rtow_kernels.hip, pair_slab): the axis the
-  // view direction is most perpendicular to.  RTOW_NO_SLAB_TEST switches it off, RTOW_SLAB_AXIS forces an axis
-  // (measurements and tests; the image does not depend on it).
-  int slab_axis = c->slab_axis;
+  // What the camera rays of a wave see before the filter (rtow_kernels.hip): by default the bundle test
+  // (scan_bundle: the table against the wave's 64 rays as a whole).  For measurements and tests - the image does not
+  // depend on it: RTOW_NO_SLAB_TEST = nothing, every ray screens every sphere itself; RTOW_CAMERA_SCREEN=slab = the
+  // slab test along the axis the view direction is most perpendicular to (pair_slab), RTOW_SLAB_AXIS=0|1|2 = that
+  // test along a given axis.
+  int slab_axis = rtow::kBundleTest;
   if (getenv("RTOW_NO_SLAB_TEST")) slab_axis = -1;
   else if (const char* e = getenv("RTOW_SLAB_AXIS")) { const int v = atoi(e); if (v >= 0 && v <= 2) slab_axis = v; }
+  else if (const char* s = getenv("RTOW_CAMERA_SCREEN")) { if (!strcmp(s, "slab")) slab_axis = c->slab_axis; }
   if (n_pixels) rtow::launch_trace(p, slab_axis, grid, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));

@@ -85,7 +85,9 @@ struct ScatterParams {
 };
 void launch_scatter(const ScatterParams& p, hipStream_t stream);
 
-// slab_axis: axis of the slab test the camera rays see before the filter (0, 1, 2; see pair_slab), or -1 for none
+// slab_axis: what the camera rays see before the filter: the slab test along axis 0, 1 or 2 (see pair_slab), the
+// bundle test (kBundleTest; see scan_bundle), or -1 for nothing
+constexpr int kBundleTest = 3;
 void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);

@@ -610,6 +610,91 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
 
+// Closest hit of the camera rays of a PRIMARY iteration when those rays form a narrow bundle (64 samples of one
+// pixel through a small lens, or of a few neighbouring pixels).  The wave first walks the table with the SPHERES
+// spread over its lanes and tests each against the bundle as a whole - one axis ray (a, w) and the spread of the 64
+// rays about it - and only the groups with a sphere near the bundle go through the per-ray filter and the exact
+// tests.  The list stays a plain list, walked from the first entry to the last for every bundle; no structure is
+// kept over the scene or between iterations.
+//
+// Bound.  Let delta_o >= |o_i - a| and delta_u >= |u_i - w| for every ray i of the wave (unit directions).  The point
+// of ray i nearest to a centre c is o_i + s u_i with |s| <= |c - o_i| <= |c - a| + delta_o, and that point lies within
+// delta_o + |s| delta_u of the axis point a + s w.  A sphere that ray i's exact test accepts has its centre within |r|
+// of the ray's line, hence within
+//     |r| + rho(c),   rho(c) = delta_o + (|c - a| + delta_o) delta_u
+// of the axis line.  The square root is avoided with |c - a| <= q / (2 L) + L / 2 for q = |c - a|^2 and any L > 0
+// (tight at |c - a| = L; L = the camera's distance from the world origin, floored at 1):
+//     rho(c) <= A + B q,   A = delta_o (1 + delta_u) + delta_u L / 2,   B = delta_u / (2 L).
+// A group goes on unless, for all four of its spheres,  q - ((c - a).w)^2  >  (|r| + A + B q)^2 + slack.
+// Roundings: the spreads are measured on the binary32 rays the filter uses, which lie within 2^-24 |o|_1 and 2^-21
+// of the binary64 rays; the table's centres within 2^-24 |c|_1 of the binary64 centres; the left side is evaluated
+// with an absolute error below 2^-19 q.  delta_o, delta_u are therefore enlarged by 2^-10 of themselves plus
+// 2^-20 (|a|_1 + cmax + 1) and 2^-20, |r| (a raw v_sqrt_f32 of the table's r^2) by 2^-16 of itself, and slack is
+// 2^-18 q.  A NaN anywhere lets the group through (the comparison is written so), where the filter decides as before.
+// Entries that must never pass (padding, spheres tested elsewhere) have an all-zero record here and k = +inf in the
+// filter: if the bundle test lets one through, the filter stops it.
+//
+// How far the bundle test thins the table depends on the rays: one pixel's samples through the book camera's lens
+// leave a handful of groups; a wave whose lanes belong to many pixels, or a wide lens, leaves more, and a wave that
+// straddles the end of an image row leaves nearly all of them - the scan then costs the bundle test on top of a
+// plain scan, and returns the same hits.
+template <bool K_LDS, bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void scan_bundle(geom_ptr geom, ExactPtr exact, const f4v* nk_lds, CandList<SHORT>& cand,
+                                                   int n_groups, float cmax, bool live, f3 o, f3 u, f3 a, f3 w,
+                                                   const PrimaryCtx& pc RTOW_PROF_PARAM) {
+  if (n_groups <= 0) return;
+  ScanRay r = scan_ray(o, u, cmax);
+  if (!live) r.ozt.y = INFINITY;
+  // spread of the wave's rays about the axis: two wave-wide maxima of non-negative numbers, taken as integers
+  // (the bit patterns order like the values, NaN above them all) with LDS atomics on two words of the empty list
+  float A, B;
+  {
+    const f3 eo = {o.x - a.x, o.y - a.y, o.z - a.z}, eu = {u.x - w.x, u.y - w.y, u.z - w.z};
+    const lds_u32_ptr red = (lds_u32_ptr)(uint32_t*)cand.list;
+    if (cand.lane == 0) { red[0] = 0u; red[1] = 0u; }
+    lds_order();
+    __hip_atomic_fetch_max(red, __float_as_uint(dot3(eo, eo)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_max(red + 1, __float_as_uint(dot3(eu, eu)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    lds_order();
+    const float mo = __uint_as_float(red[0]), mu = __uint_as_float(red[1]);
+    lds_order();   // read before the list is used again
+    const float delta_o = fmaf(__builtin_amdgcn_sqrtf(mo), 1.0f + 0x1p-10f, 0x1p-20f * (fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + cmax + 1.0f));
+    const float delta_u = fmaf(__builtin_amdgcn_sqrtf(mu), 1.0f + 0x1p-10f, 0x1p-20f);
+    const float L = __builtin_amdgcn_sqrtf(fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, 1.0f))));
+    A = (delta_o * (1.0f + delta_u) + 0.5f * delta_u * L) * (1.0f + 0x1p-10f);
+    B = 0.5f * delta_u * __builtin_amdgcn_rcpf(L) * (1.0f + 0x1p-10f);
+  }
+  const nk_lds_ptr nk = (nk_lds_ptr)nk_lds;
+  for (int g0 = 0; g0 < n_groups; g0 += 64) {
+    const int g = g0 + (int)cand.lane;
+    bool near = false;
+    if (g < n_groups) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f4v sp = exact[4 * g + i];   // (cx, cy, cz, r^2)
+        const float ocx = sp.x - a.x, ocy = sp.y - a.y, ocz = sp.z - a.z;
+        float q = ocx * ocx; q = fmaf(ocy, ocy, q); q = fmaf(ocz, ocz, q);
+        float b = ocx * w.x; b = fmaf(ocy, w.y, b); b = fmaf(ocz, w.z, b);
+        const float dist2 = fmaf(-b, b, q);
+        const float reach = fmaf(__builtin_amdgcn_sqrtf(sp.w), 1.0f + 0x1p-16f, fmaf(B, q, A));
+        const float rhs = fmaf(q, 0x1p-18f, reach * reach);
+        near = near || !(dist2 > rhs);
+      }
+    }
+    uint64_t m = __ballot(near);
+    while (m != 0) {
+      const int gg = g0 + (int)__builtin_ctzll(m);
+      m &= m - 1;
+      RTOW_COUNT(24, 1);
+      f4v ka = {0, 0, 0, 0};
+      const GroupRec grp = load_group<K_LDS, false>(geom, gg, ka, nullptr);
+      if (K_LDS) ka = nk[gg];
+      group_test<true, -1, false, !K_LDS>(grp, ka, nk, 4 * gg, exact, cand, r, f2v{0.0f, 0.0f}, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
+    }
+  }
+  cand_drain<true>(cand, exact, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
+}
+
 // The same closest-hit query for a wave that has only a few paths left (the end of a frame, when no
 // work is left to refill the idle lanes): instead of every lane walking the whole table for its own
 // ray, the rays are taken one at a time and the TABLE is spread over the 64 lanes - lane L screens
@@ -758,7 +843,8 @@ static_assert(kPoolFields >= 14, "the pool region also holds seven doubles per l
 // K_LDS: -k per sphere in LDS (tables up to kMaxSpheresKInLds entries).  X_LDS: the records of the
 // exact test (16 bytes per sphere) in LDS as well (tables up to kMaxSpheresExactInLds entries): a
 // round of exact tests then waits for LDS, not for L2, and the survivor list has 16-bit entries.
-// SLAB_AXIS: the axis of the slab test that camera rays see before the filter (0, 1, 2), or -1 for none.
+// SLAB_AXIS: what camera rays see before the filter: the slab test along axis 0, 1 or 2, the bundle test
+// (kBundleTest, see scan_bundle), or nothing (-1: every ray screens every sphere itself).
 template <bool K_LDS, bool X_LDS, int SLAB_AXIS>
 __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
   // LDS: [4 waves][WaveLds::kTotal], then (K_LDS) -k per sphere, then (X_LDS) the exact-test records
@@ -1019,10 +1105,23 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         // rmax (the largest radius in the binary32 table) sits behind the camera in the kernel arguments
         typedef const float __attribute__((address_space(4)))* karg_f32_ptr;
         static_assert(offsetof(TraceParams, rmax) == sizeof(CameraParams64), "rmax follows the camera");
-        f2v pre = {0.0f, 0.0f};
-        if (SLAB_AXIS >= 0) pre = slab_operands<SLAB_AXIS < 0 ? 0 : SLAB_AXIS>(so, su, KARG(cmax), ((karg_f32_ptr)cf)[2 * 19]);
-        if (X_LDS) scan_regular<true, K_LDS, SLAB_AXIS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
-        else scan_regular<true, K_LDS, SLAB_AXIS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+        if constexpr (SLAB_AXIS == kBundleTest) {
+          // axis of the bundle: from the middle of the lens to the point the wave's first ray aims at (any axis is
+          // valid - the spread of the rays is measured about it - this one sits in the middle of the lens)
+          const f3 ax = {(float)cf[0], (float)cf[1], (float)cf[2]};
+          const f3 aim = {__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, so.x + sd.x))) - ax.x,
+                          __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, so.y + sd.y))) - ax.y,
+                          __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, so.z + sd.z))) - ax.z};
+          f3 aw;
+          segment_begin(aim, aw, tmin_unused);
+          if (X_LDS) scan_bundle<K_LDS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, ax, aw, pc RTOW_PROF_ARG);
+          else scan_bundle<K_LDS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, ax, aw, pc RTOW_PROF_ARG);
+        } else {
+          f2v pre = {0.0f, 0.0f};
+          if (SLAB_AXIS >= 0) pre = slab_operands<SLAB_AXIS < 0 ? 0 : SLAB_AXIS>(so, su, KARG(cmax), ((karg_f32_ptr)cf)[2 * 19]);
+          if (X_LDS) scan_regular<true, K_LDS, SLAB_AXIS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+          else scan_regular<true, K_LDS, SLAB_AXIS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+        }
         RTOW_STAMP(t_scan1);
       }
       // ---- the camera rays' hits: sky ends the path (binary64, raytracer.nim:18-20), a hit scatters
@@ -1240,6 +1339,7 @@ void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStrea
     case 0: launch_trace_axis<0>(p, grid_blocks, stream); break;
     case 1: launch_trace_axis<1>(p, grid_blocks, stream); break;
     case 2: launch_trace_axis<2>(p, grid_blocks, stream); break;
+    case kBundleTest: launch_trace_axis<kBundleTest>(p, grid_blocks, stream); break;
     default: launch_trace_axis<-1>(p, grid_blocks, stream); break;
   }
 }
