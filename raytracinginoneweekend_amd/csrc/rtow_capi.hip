@@ -542,15 +542,16 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   HIP_TRY(hipMemsetAsync(t.counters, 0, kCounterBytes, c->stream));
   if (first_sample == 0 && n_pixels) HIP_TRY(hipMemsetAsync(t.accum, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  // What the camera rays of a wave see before the filter (rtow_kernels.hip): by default the bundle test
-  // (scan_bundle: the table against the wave's 64 rays as a whole).  For measurements and tests - the image does not
-  // depend on it: RTOW_NO_SLAB_TEST = nothing, every ray screens every sphere itself; RTOW_CAMERA_SCREEN=slab = the
-  // slab test along the axis the view direction is most perpendicular to (pair_slab), RTOW_SLAB_AXIS=0|1|2 = that
-  // test along a given axis.
-  int slab_axis = rtow::kBundleTest;
+  // What the camera rays of a wave see before the filter (rtow_kernels.hip): by default the slab test along the axis
+  // the view direction is most perpendicular to (pair_slab) - every ray still tests every sphere itself.  The image
+  // does not depend on the choice; for measurements and tests: RTOW_NO_SLAB_TEST = nothing in front of the filter,
+  // RTOW_SLAB_AXIS=0|1|2 = the slab test along a given axis, RTOW_CAMERA_SCREEN=bundle = the bundle test (scan_bundle:
+  // the table against the wave's 64 rays as a whole).  The bundle test decides about a sphere once per wave instead
+  // of once per ray, which is culling by ray packets rather than brute force: it is an option, never the default.
+  int slab_axis = c->slab_axis;
   if (getenv("RTOW_NO_SLAB_TEST")) slab_axis = -1;
   else if (const char* e = getenv("RTOW_SLAB_AXIS")) { const int v = atoi(e); if (v >= 0 && v <= 2) slab_axis = v; }
-  else if (const char* s = getenv("RTOW_CAMERA_SCREEN")) { if (!strcmp(s, "slab")) slab_axis = c->slab_axis; }
+  else if (const char* s = getenv("RTOW_CAMERA_SCREEN")) { if (!strcmp(s, "bundle")) slab_axis = rtow::kBundleTest; }
   if (n_pixels) rtow::launch_trace(p, slab_axis, grid, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));

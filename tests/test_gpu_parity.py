@@ -720,7 +720,8 @@ def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
             r.setCamera(initCamera(point(*cam["look_from"]), point(*cam["look_at"]), vec3(0, 1, 0), vfov=cam["vfov"],
                                    aspectRatio=W / H, aperture=cam["aperture"], focusDist=cam["focus"]))
             ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H, **cam), W, H, spp, depth, threads=16)
-            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}, {"RTOW_SLAB_AXIS": "0"}, {"RTOW_SLAB_AXIS": "1"}, {"RTOW_SLAB_AXIS": "2"}):
+            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}, {"RTOW_SLAB_AXIS": "0"}, {"RTOW_SLAB_AXIS": "1"}, {"RTOW_SLAB_AXIS": "2"},
+                        {"RTOW_CAMERA_SCREEN": "bundle"}):
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
@@ -728,6 +729,37 @@ def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
                     monkeypatch.delenv(k)
                 _check_bit_exact(got, ref)
                 assert r.stats()["ray_segments"] == ref[3], env
+
+
+def test_optional_bundle_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
+    """RTOW_CAMERA_SCREEN=bundle (an option for measurements, never the default: it decides about a sphere once per
+    wave, not once per ray) puts a test of the table against the wave's 64 camera rays as a whole in front of the
+    filter.  Like the slab test it may only drop spheres that every ray of the wave misses.  Checked where the bundle
+    is narrow (many samples of one pixel per wave: the case it is built for), where a wave spans pixels and row ends
+    (few samples), through a wide lens, and on a table beyond the LDS sizes: hit ids, sums, pixels and segment counts
+    equal the mirror's, which has no such test."""
+    R = _R()
+    cases = [
+        (11, 48, 32, 130, dict(look_from=(13, 2, 3), look_at=(0, 0, 0), vfov=20.0, aperture=0.1, focus=10.0)),
+        (11, 37, 23, 5, dict(look_from=(13, 2, 3), look_at=(0, 0, 0), vfov=20.0, aperture=0.1, focus=10.0)),
+        (11, 40, 30, 70, dict(look_from=(3, 1.5, 2), look_at=(0, 0.5, 0), vfov=50.0, aperture=2.0, focus=3.5)),
+        (11, 40, 30, 64, dict(look_from=(1, 0.5, 1), look_at=(0, 0.4, -3), vfov=80.0, aperture=0.0, focus=1.0)),
+        (35, 40, 24, 66, dict(look_from=(13, 2, 3), look_at=(0, 0, 0), vfov=20.0, aperture=0.1, focus=10.0)),
+        (50, 32, 18, 64, dict(look_from=(13, 2, 3), look_at=(0, 0, 0), vfov=20.0, aperture=0.1, focus=10.0)),
+    ]
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    monkeypatch.setenv("RTOW_CAMERA_SCREEN", "bundle")
+    with R.Renderer(0) as r:
+        for half, W, H, spp, cam in cases:
+            arr, n = oracle.random_scene(half_extent=half)[:2]
+            r.setWorld(R.randomScene(halfExtent=half))
+            r.setCamera(initCamera(point(*cam["look_from"]), point(*cam["look_at"]), vec3(0, 1, 0), vfov=cam["vfov"],
+                                   aspectRatio=W / H, aperture=cam["aperture"], focusDist=cam["focus"]))
+            ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H, **cam), W, H, spp, 50, threads=16)
+            got = r.renderRows(W, H, spp, 50, want_accum=True, want_hit_id=True)
+            _check_bit_exact(got, ref)
+            assert r.stats()["ray_segments"] == ref[3], (half, W, H, spp)
 
 
 def test_smallest_frame_and_depth_one(oracle, book_scene):
