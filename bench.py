@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks "
                          "(ranks share devices, rows are gathered through host memory); not a valid benchmark")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="with one rank: run the multi-GPU code path anyway (process group, RCCL all_gather of the rows "
+                         "on the render stream, assembly, comparison with a whole-frame render); a check of the plumbing "
+                         "on a one-GPU box, not a benchmark")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -161,11 +165,18 @@ def main():
         # touched a GPU or imported torch, and nothing is exec'ed: the workers are fresh child processes.
         raise SystemExit(launch_workers(args.gpus))
 
+    if args.rehearse_collective and "RANK" not in os.environ:   # a one-rank job of its own
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
+        sock.close()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         args.gpus = world
+    sharded = world > 1 or args.rehearse_collective   # rows are dealt to ranks and gathered
 
     width, height, spp, depth, half_extent, lam, met = WORKLOADS[args.workload]
     if args.spp:
@@ -174,7 +185,7 @@ def main():
 
     dist = torch = None
     device = local_rank
-    if world > 1:
+    if sharded:
         import torch
         import torch.distributed as dist
         if args.backend == "gloo":
@@ -190,27 +201,31 @@ def main():
     world_scene = R.randomScene(halfExtent=half_extent, lambertBelow=lam, metalBelow=met)
     n_spheres = len(world_scene)
     tile = 4
-    rows = None if world == 1 else multigpu.tile_rows(height, world, rank, tile)
+    rows = multigpu.tile_rows(height, world, rank, tile) if sharded else None
     n_rows = height if rows is None else len(rows)
 
     # Frames in flight: PIPELINE contexts (each its own stream, accumulators and image) take the
     # steps in turn, so that the tail of one frame - a few wavefronts finishing their longest paths,
     # the resolve kernel, the gather of the rows - overlaps the start of the next frame.
     depth_in_flight = max(1, args.pipeline)
-    renderers, gatherers, images = [], [], []
+    renderers, gatherers, images, streams = [], [], [], []
     for _ in range(depth_in_flight):
         r = R.Renderer(device)
         r.setWorld(world_scene)
         r.setCamera(R.bookCamera(width / height))
         renderers.append(r)
-        if world > 1:
-            g = multigpu.TileGatherer(height, width, world, rank, f"cuda:{device}" if args.backend == "nccl" else "cpu", tile)
+        if sharded:
+            g = multigpu.TileGatherer(height, width, world, rank, f"cuda:{device}" if args.backend == "nccl" else "cpu", tile,
+                                      always_collective=args.rehearse_collective)
             gatherers.append(g)
             images.append(g.local if args.backend == "nccl"
                           else torch.empty((n_rows, width, 3), dtype=torch.uint8, device=f"cuda:{device}"))
+            # the context's own stream as a torch stream: the gather of a frame is enqueued on it right behind the
+            # frame's kernels, so no host round trip sits between a frame and its gather
+            streams.append(torch.cuda.ExternalStream(r.stream(), device=f"cuda:{device}") if args.backend == "nccl" else None)
 
     def sync_all():
-        if world > 1:
+        if sharded:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -219,17 +234,17 @@ def main():
         k = i % depth_in_flight
         renderers[k].renderAsync(width, height, spp, depth, seed, rows=rows,
                                  rgb_dev=images[k].data_ptr() if images else None)
+        if sharded and args.backend == "nccl":
+            with torch.cuda.stream(streams[k]):
+                gatherers[k].gather()   # stream-ordered behind the frame: the collective and rank 0's row scatter
 
     def finish(i):
         k = i % depth_in_flight
-        renderers[k].sync()
+        renderers[k].sync()   # the context's stream: the frame and (RCCL) the gather enqueued behind it
         st = renderers[k].stats()
-        if world > 1:
-            if args.backend != "nccl":
-                gatherers[k].local[:n_rows].copy_(images[k])
+        if sharded and args.backend != "nccl":
+            gatherers[k].local[:n_rows].copy_(images[k])
             gatherers[k].gather()
-            if args.backend == "nccl":
-                torch.cuda.current_stream().synchronize()  # the rows are read before this context renders again
         return st
 
     def run(n_steps):
@@ -242,7 +257,7 @@ def main():
             out.append(finish(i))
         return out
 
-    if world > 1:   # communicator set-up and the first collective stay out of the timed region even with --warmup 0
+    if sharded:   # communicator set-up and the first collective stay out of the timed region even with --warmup 0
         for g in gatherers:
             g.gather()
         sync_all()
@@ -305,12 +320,12 @@ def main():
 
     # the frame assembled from all ranks' tiles against the same frame rendered whole on rank 0
     image_verified = None
-    if world > 1 and rank == 0:
+    if sharded and rank == 0:
         last = gatherers[(n_serial - 1) % depth_in_flight].full          # gathered by the last step
         whole = renderers[0].renderRows(width, height, spp, depth, seed)[0]
         image_verified = bool((last.cpu().numpy() == whole).all())
 
-    if world > 1:
+    if sharded:
         red_dev = f"cuda:{device}" if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -349,8 +364,9 @@ def main():
                 "workload": f"{args.workload}: book-1 random-spheres scene, {width}x{height}, spp {spp}, depth {depth}, "
                             f"{n_spheres} spheres in a linear list, seed 0xE7",
                 "width": width, "height": height, "spp": spp, "max_depth": depth, "n_spheres": n_spheres,
-                "parallelism": "single GPU" if world == 1 else (
-                    f"interleaved {tile}-row tiles over {world} GPUs + RCCL all_gather of 8-bit rows" if args.backend == "nccl"
+                "parallelism": "single GPU" if not sharded else (
+                    f"interleaved {tile}-row tiles over {world} GPUs + RCCL all_gather of 8-bit rows on the render stream"
+                    + (" -- REHEARSAL of the collective path with one rank" if args.rehearse_collective else "") if args.backend == "nccl"
                     else f"REHEARSAL: {world} gloo ranks sharing devices (not a benchmark)"),
                 "frames_in_flight": depth_in_flight,
                 "gathered_image_equals_single_gpu_render": image_verified,
@@ -400,13 +416,13 @@ def main():
             },
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, depth, seed)
         print(json.dumps(out), flush=True)
 
     for r in renderers:
         r.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

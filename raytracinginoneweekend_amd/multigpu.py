@@ -56,15 +56,18 @@ class TileGatherer:
     the destination rank, one row scatter.  `local` is the tensor the renderer writes into (rows of
     this rank first, padding rows after them)."""
 
-    def __init__(self, height, width, world_size, rank, device, tile=4, group=None, dst=0):
+    def __init__(self, height, width, world_size, rank, device, tile=4, group=None, dst=0, always_collective=False):
         import torch
         self.height, self.width, self.world, self.rank, self.tile = height, width, world_size, rank, tile
         self.group, self.dst = group, dst
+        # a one-rank job normally skips the collective; always_collective runs it anyway (a rehearsal of the
+        # multi-GPU path on one GPU: needs an initialised process group)
+        self.collective = world_size > 1 or always_collective
         # The collective is chosen once, from the backend: gloo has no flat all_gather_into_tensor.
         # Errors of the chosen collective propagate - a rank that fell back to another collective
         # after a failure would leave its peers waiting in the first one.
         self.flat = True
-        if world_size > 1:
+        if self.collective:
             import torch.distributed as dist
             self.flat = dist.get_backend(group) != "gloo"
         self.rows = tile_rows(height, world_size, rank, tile)
@@ -84,7 +87,7 @@ class TileGatherer:
     def gather(self):
         """All ranks call this after their render has finished; returns the frame on `dst`."""
         import torch.distributed as dist
-        if self.world == 1:
+        if not self.collective:
             return self.local[: len(self.rows)]
         if self.flat:
             dist.all_gather_into_tensor(self.recv.view(-1), self.local.view(-1), group=self.group)

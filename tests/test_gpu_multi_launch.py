@@ -41,3 +41,22 @@ def test_bench_single_gpu_line_is_unchanged_by_the_launcher():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["roofline"]["kernel"] == "rtow_trace_kernel" and out["cpu_baseline"] is None
     assert 0.0 < out["roofline"]["frac"] < 2.0
+
+
+def test_bench_collective_path_with_one_rank_over_rccl():
+    """The code the multi-GPU benchmark runs per step - process group on the RCCL backend, the context's stream as a
+    torch stream, all_gather_into_tensor of the padded rows enqueued behind the frame on that stream, rank 0's row
+    scatter - with one rank on the box's one GPU (--rehearse-collective): three frames in flight must come back
+    assembled into the image of a whole-frame render, and the process must exit cleanly."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-collective", "--steps", "5", "--warmup", "1",
+                        "--spp", "8", "--pipeline", "3", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and "RCCL all_gather" in out["config"]["parallelism"] and "REHEARSAL" in out["config"]["parallelism"]
+    assert out["config"]["gathered_image_equals_single_gpu_render"] is True
+    assert out["config"]["segments_per_step"] >= 1200 * 800 * 8
