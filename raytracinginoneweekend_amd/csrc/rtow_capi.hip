@@ -155,7 +155,7 @@ struct rtow_ctx {
   int n_spheres = 0, n_geom_pad = 0, n_big = 0;
   DevBuf geom, geom_rr, geom_nk, geom_slab, geom64, big, shade;
   float cmax = 0.0f;
-  float rmax = 0.0f;                          // largest |radius| among the spheres of the binary32 table
+  float slab_inv_rmin = 1.0f;                 // 1 / (smallest group radius of the slab test), see set_scene_impl
   int slab_axis = 1;                          // axis of the camera rays' slab test, chosen from the camera
   rtow::CameraParams64 cam;
 
@@ -377,11 +377,14 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   std::vector<float> nk((size_t)n_alloc, -INFINITY);
   // the scene as given, for the binary64 tests of primary rays; every other table holds binary32 roundings
   std::vector<double4> geom64((size_t)(n > 0 ? n : 1), make_double4(0.0, 0.0, 0.0, 1.0));
-  float cmax = 0.0f, rmax = 0.0f;
-  // tables that fit LDS take -k from there, and the last four floats of a group carry -r^2 for the slab test
-  // (+inf, the initial value, for the entries that must never pass)
+  float cmax = 0.0f;
+  // The slab test of the camera rays (rtow_kernels.hip, pair_slab) compares a ray's distance to each of a group's
+  // four centres with ONE radius per group: the largest |r| among the group's spheres (a group without a sphere of the
+  // binary32 table gets -1 and never passes).  Tables that fit LDS take -k from there, which leaves the last four
+  // floats of a group record free: the first of them carries that radius; larger tables keep it in an array of its own.
   const bool slab_table = n_pad <= rtow::kMaxSpheresKInLds;
-  std::vector<float> slab(slab_table ? 4 : (size_t)n_alloc, INFINITY);   // larger tables: an array of its own
+  const int n_groups_alloc = n_alloc / 4;
+  std::vector<float> group_radius((size_t)n_groups_alloc, -1.0f);
   for (int j = 0; j < n; ++j) {
     geom64[j] = make_double4((double)cx[j], (double)cy[j], (double)cz[j], (double)radius[j]);
     const float fx = (float)cx[j], fy = (float)cy[j], fz = (float)cz[j];
@@ -393,11 +396,9 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
       geom_at(j, 3) = (float)(c2 - (double)r * r);
       exact[j] = make_float4(fx, fy, fz, r * r);
       nk[j] = -geom_at(j, 3);
-      if (slab_table) geom_at(j, 3) = -(r * r);
-      else slab[j] = -(r * r);
+      if (std::fabs(r) > group_radius[(size_t)(j / 4)]) group_radius[(size_t)(j / 4)] = std::fabs(r);
       const float reach = (float)std::sqrt(c2) + std::fabs(r);
       if (reach > cmax) cmax = reach;
-      if (std::fabs(r) > rmax) rmax = std::fabs(r);
     }
     if (is_big) {
       rtow::BigSphere b;
@@ -416,6 +417,20 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
       s.ab = 0.f;
     }
   }
+  // The test's slack is absolute (rounding of a value of the size of the scene) and enters as a scale of the ray,
+  // 1 / (1 + slack / smallest group radius): radii below 2^-8 of the scene's extent are raised to that, so that one
+  // tiny sphere cannot blunt the test for all the others (a larger radius only lets more groups through).
+  float slab_rmin = INFINITY;
+  for (int g = 0; g < n_groups_alloc; ++g) {
+    float& rg = group_radius[(size_t)g];
+    if (rg > 0.0f) {
+      rg = std::max(rg, cmax * 0x1p-8f);
+      slab_rmin = std::min(slab_rmin, rg);
+    }
+    if (slab_table)
+      for (int k = 0; k < 4; ++k) geom[(size_t)g * 16 + 12 + (size_t)k] = k == 0 ? rg : 0.0f;
+  }
+  const std::vector<float>& slab = group_radius;
   HIP_TRY(c->geom64.reserve(sizeof(double4) * geom64.size()));
   HIP_TRY(hipMemcpyAsync(c->geom64.p, geom64.data(), sizeof(double4) * geom64.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
@@ -429,7 +444,7 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   HIP_TRY(hipMemcpyAsync(c->geom_rr.p, exact.data(), sizeof(float4) * exact.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->geom_nk.p, nk.data(), sizeof(float) * nk.size(), hipMemcpyHostToDevice, c->stream));
   c->cmax = cmax;
-  c->rmax = rmax;
+  c->slab_inv_rmin = std::isfinite(slab_rmin) ? 1.0f / slab_rmin : 1.0f;
   HIP_TRY(hipMemcpyAsync(c->shade.p, shade.data(), sizeof(rtow::SphereShade) * shade.size(), hipMemcpyHostToDevice, c->stream));
   if (!big.empty())
     HIP_TRY(hipMemcpyAsync(c->big.p, big.data(), sizeof(rtow::BigSphere) * big.size(), hipMemcpyHostToDevice, c->stream));
@@ -506,7 +521,7 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   p.geom64 = (const double4*)c->geom64.p; p.n_list = c->n_spheres;
   p.geom_slab = (const float*)c->geom_slab.p;
   p.cmax = c->cmax;
-  p.rmax = c->rmax;
+  p.slab_inv_rmin = c->slab_inv_rmin;
   p.pad_ = 0.0f;
   p.big = (const rtow::BigSphere*)c->big.p; p.n_big = c->n_big;
   p.shade = (const rtow::SphereShade*)c->shade.p;

@@ -15,14 +15,14 @@ constexpr int kMaxSpheresKInLds = 4096;  // up to this many table entries the fi
 
 struct TraceParams {
   CameraParams64 cam;        // must stay first: the kernel reads it straight from its argument segment
-  float rmax;                // largest |radius| in the binary32 table (scales the slab test's slack)
+  float slab_inv_rmin;       // 1 / (smallest group radius of the slab test): turns the test's absolute slack into a scale of the ray
   float pad_;
   const float* geom;         // n_geom_pad/4 + 2 groups of 16 floats (layout: scan_regular), list order; the last four of a group
                              // are k for tables beyond kMaxSpheresKInLds entries, -r^2 (slab test) for the others
   const float* geom_nk;      // -k per list entry (n_geom_pad + 8 values): copied to LDS by each workgroup
   const float4* geom_exact;  // (cx, cy, cz, r^2) per list entry, fetched per lane for the exact test
   const double4* geom64;     // (cx, cy, cz, r) per list entry in binary64: the exact test of primary rays
-  const float* geom_slab;    // -r^2 per table entry (+inf: never passes) for tables beyond kMaxSpheresKInLds entries
+  const float* geom_slab;    // the slab test's radius per group of four (negative: never passes) for tables beyond kMaxSpheresKInLds entries
   int n_geom_pad;
   int n_list;                // spheres in the list (= entries of geom64 and shade)
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin

@@ -137,41 +137,46 @@ static __device__ __forceinline__ f2v pk_fma_bcast(f2v a, f2v b, f2v c) {
 // PRIMARY iteration are consecutive samples of one pixel).  Component k of (c - o) x u is the distance between
 // the sphere's centre and the ray's line as seen along axis k, times a factor <= 1: a sphere the ray hits has
 //     | c_i u_j - c_j u_i - (o_i u_j - o_j u_i) | <= |r|          (i, j = the two other axes, in cyclic order).
-// Three packed instructions per pair of spheres (two for the value, one for value^2 - r^2) against the
-// filter's seven; a group of four goes on to the filter only if some lane's ray passes, which for 64 samples
-// of one pixel is one group in eleven on the book scene.  The host picks k per launch: the axis the view
-// direction is most perpendicular to (the projection then shortens the rays least).
-// `pre` = (o_j u_i - o_i u_j, slack); -r^2 of the four spheres comes with the group (+inf for the entries that
-// never pass).  Every ray is still tested against every sphere; the slack is 128 times the rounding error of
-// the value (see slab_operands), so the test drops no sphere that is hit.
-template <int AXIS>
-static __device__ __forceinline__ f2v pair_slab(const f2v ci, const f2v cj, const f2v nrr, const ScanRay& r, const f2v pre) {
-  f2v t, v, g;
-  // t = cj * (-u_i) + m, v = ci * u_j + t: u_i and u_j are halves of the pairs the filter already keeps
-  // (r.uxy = u.x, u.y; low half of r.uzn = u.z), m is the low half of pre
-  if (AXIS == 0) {   // i = y, j = z
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(r.uxy), "v"(pre));
-    v = pk_fma_bcast<0, 0>(ci, r.uzn, t);
-  } else if (AXIS == 1) {   // i = z, j = x
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(r.uzn), "v"(pre));
-    v = pk_fma_bcast<0, 0>(ci, r.uxy, t);
-  } else {   // i = x, j = y
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(r.uxy), "v"(pre));
-    v = pk_fma_bcast<1, 0>(ci, r.uxy, t);
-  }
-  g = __builtin_elementwise_fma(v, v, nrr);   // value^2 - r^2 (left to the compiler: it then knows the result is no signalling NaN
-  return g;                                   // and does not quiet it again before taking the minimum)
+// Two packed instructions per pair of spheres give the value for every (ray, sphere) pair, and the smallest |value|
+// of a group's four spheres is compared with ONE radius per group, the largest |r| among the four (a scalar that
+// comes with the group record): per group four packed FMAs, two minima and a compare - seven instructions against
+// the filter's seventeen - and the group goes on to the filter only if some lane's ray passes, which for 64 samples
+// of one pixel is one group in eleven on the book scene.  The host picks k per launch: the axis the view direction
+// is most perpendicular to (the projection then shortens the rays least).
+// Rounding.  The value evaluated in binary32 on rounded operands is off by less than 2^-21 (|o| + cmax); the test
+// allows delta = 2^-14 (|o|_1 + cmax), 128 times that.  An absolute slack next to a per-group radius would cost an
+// addition per group, so it enters as a scale of the RAY instead: the ray's operands (u_i, u_j, m) are multiplied by
+// s = 1 / (1 + delta / rmin), rmin = the smallest group radius of the table, and |s value| <= rg is implied by
+// |value| <= rg + delta for every rg >= rmin.  Every ray is still tested against every sphere; the test drops no
+// sphere that is hit.
+// sl = s (u_i, u_j), pre.x = s (o_j u_i - o_i u_j); returns s * value for the two spheres.
+static __device__ __forceinline__ f2v pair_slab(const f2v ci, const f2v cj, const f2v sl, const f2v pre) {
+  f2v t;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(t) : "s"(cj), "v"(sl), "v"(pre));
+  return pk_fma_bcast<1, 0>(ci, sl, t);
 }
 
-// pre = (m, slack) of pair_slab for the ray (o, u) and axis AXIS.  Error of the value evaluated in binary32 on
-// rounded operands: below 2^-21 (|o| + cmax); the test allows delta = 2^-14 (|o|_1 + cmax), i.e.
-// value^2 - r^2 <= delta (2 rmax + delta).
+// min(|a.x|, |a.y|, |b.x|, |b.y|): the source modifiers take the absolute values
+static __device__ __forceinline__ float min_abs4(f2v a, f2v b) {
+  float m;
+  asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(a.x), "v"(a.y), "v"(b.x));
+  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(m) : "v"(b.y), "v"(m));
+  return m;
+}
+
+// The ray's operands of pair_slab for axis AXIS: sl in the result's .lo, pre in its .hi.
+struct SlabRay { f2v sl, pre; };
 template <int AXIS>
-static __device__ __forceinline__ f2v slab_operands(f3 o, f3 u, float cmax, float rmax) {
+static __device__ __forceinline__ SlabRay slab_operands(f3 o, f3 u, float cmax, float inv_rmin) {
   const float oi = AXIS == 0 ? o.y : AXIS == 1 ? o.z : o.x, oj = AXIS == 0 ? o.z : AXIS == 1 ? o.x : o.y;
   const float ui = AXIS == 0 ? u.y : AXIS == 1 ? u.z : u.x, uj = AXIS == 0 ? u.z : AXIS == 1 ? u.x : u.y;
   const float delta = (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + cmax) * 0x1p-14f;
-  return f2v{fmaf(oj, ui, -(oi * uj)), delta * fmaf(2.0f, rmax, delta)};
+  // (the hardware reciprocal is within 1 ulp; the factor below keeps s on the safe side of it)
+  const float s = __builtin_amdgcn_rcpf(fmaf(delta, inv_rmin, 1.0f)) * (1.0f - 0x1p-20f);
+  SlabRay r;
+  r.sl = f2v{s * ui, s * uj};
+  r.pre = f2v{s * fmaf(oj, ui, -(oi * uj)), 0.0f};
+  return r;
 }
 
 static __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
@@ -444,10 +449,10 @@ static __device__ __forceinline__ void cand_drain(CandList<SHORT>& c, ExactPtr e
 struct GroupRec {   // centres of four spheres as packed pairs
   f8v a;            // cx0 cx1 cy0 cy1 cz0 cz1 cx2 cx3
   f4v b;            // cy2 cy3 cz2 cz3
-  f4v nrr;          // -r^2 of the four (loaded only for scans that run the slab test)
+  float rg;         // the group's radius for the slab test (loaded only for scans that run it)
 };
 
-typedef const f4v __attribute__((address_space(4)))* slab_ptr;   // -r^2 of a group's four spheres, one f4v per group
+typedef const float __attribute__((address_space(4)))* slab_ptr;   // the slab test's radius, one per group
 
 template <bool K_LDS, bool SLAB = false>
 static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v& nk, slab_ptr slab = nullptr) {
@@ -457,13 +462,13 @@ static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v&
     typedef const f4v __attribute__((address_space(4)))* p4;
     r.a = *(p8)(geom + g);
     r.b = *((p4)(geom + g) + 2);
-    if (SLAB) r.nrr = *((p4)(geom + g) + 3);   // -r^2 of the four spheres (tables whose -k sits in LDS keep it here)
+    if (SLAB) r.rg = *((slab_ptr)(geom + g) + 12);   // tables whose -k sits in LDS keep the slab test's radius here
   } else {
     const f16v v = geom[g];
     r.a = v.lo;
     r.b = f4v{v.s8, v.s9, v.sa, v.sb};
     nk = f4v{-v.sc, -v.sd, -v.se, -v.sf};
-    if (SLAB) r.nrr = slab[g];   // these tables use all 16 floats of a group: -r^2 comes from an array of its own
+    if (SLAB) r.rg = slab[g];   // these tables use all 16 floats of a group: the radius comes from an array of its own
   }
   return r;
 }
@@ -474,16 +479,15 @@ typedef const f4v __attribute__((address_space(3)))* nk_lds_ptr;
 // gets as far as the filter
 template <bool PRIMARY, int AXIS, bool NK_LATE, bool K_SGPR, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void group_test(const GroupRec grp, f4v nk, nk_lds_ptr nk_late, int j, ExactPtr exact,
-                                                  CandList<SHORT>& cand, const ScanRay& r, const f2v pre, f3 o, f3 u, float tmin,
+                                                  CandList<SHORT>& cand, const ScanRay& r, const SlabRay& sr, f3 o, f3 u, float tmin,
                                                   int prev, const PrimaryCtx& pc RTOW_PROF_PARAM) {
   if (AXIS >= 0) {
     // coordinates i and j of the four centres, as the pairs the group holds them in
     const f2v ci0 = AXIS == 0 ? grp.a.s23 : AXIS == 1 ? grp.a.s45 : grp.a.s01, cj0 = AXIS == 0 ? grp.a.s45 : AXIS == 1 ? grp.a.s01 : grp.a.s23;
     const f2v ci1 = AXIS == 0 ? grp.b.xy : AXIS == 1 ? grp.b.zw : grp.a.s67, cj1 = AXIS == 0 ? grp.b.zw : AXIS == 1 ? grp.a.s67 : grp.b.xy;
-    const f2v g0 = pair_slab<AXIS>(ci0, cj0, grp.nrr.xy, r, pre);
-    const f2v g1 = pair_slab<AXIS>(ci1, cj1, grp.nrr.zw, r, pre);
-    const float mn = fminf(fminf(g0.x, g0.y), fminf(g1.x, g1.y));
-    if (__ballot(mn <= pre.y) == 0) return;   // wave-uniform: no ray of the wave comes near any of the four
+    const f2v g0 = pair_slab(ci0, cj0, sr.sl, sr.pre);
+    const f2v g1 = pair_slab(ci1, cj1, sr.sl, sr.pre);
+    if (__ballot(min_abs4(g0, g1) <= grp.rg) == 0) return;   // wave-uniform: no ray of the wave comes near any of the four
     RTOW_COUNT(24, 1);
     if (NK_LATE) nk = *nk_late;
   }
@@ -555,13 +559,13 @@ static __device__ __forceinline__ void pair_step(geom_ptr geom, int g, nk_lds_pt
 template <bool PRIMARY, bool K_LDS, int AXIS, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exact, const f4v* nk_lds,
                                                     CandList<SHORT>& cand, int n_groups, float cmax, bool live, f3 o, f3 u,
-                                                    float tmin, int prev, const PrimaryCtx& pc, f2v pre RTOW_PROF_PARAM) {
+                                                    float tmin, int prev, const PrimaryCtx& pc, SlabRay sr RTOW_PROF_PARAM) {
   static_assert(AXIS < 0 || PRIMARY, "the slab test is for the camera rays");
   if (n_groups <= 0) return;
   constexpr bool SLAB = AXIS >= 0;   // the slab test runs where the wave's rays are one pixel's camera rays
   const slab_ptr slab = (SLAB && !K_LDS) ? (slab_ptr)(uintptr_t)KARG(geom_slab) : nullptr;
   ScanRay r = scan_ray(o, u, cmax);
-  if (!live) { r.ozt.y = INFINITY; pre.y = -INFINITY; }
+  if (!live) { r.ozt.y = INFINITY; sr.pre.x = INFINITY; }   // an infinite value passes neither test
   // The LDS address of -k lives in a VGPR that advances by two groups per trip; the reads then use
   // immediate offsets.  (Left to itself the compiler keeps the address in an SGPR and copies it to
   // a VGPR for every read: one more VALU instruction per group.)
@@ -601,10 +605,10 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
     if (K_LDS && !NK_LATE) kb = nk[1];
-    group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(ga, ka, NK_LATE ? nk_base + g : nk, 4 * g, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(ga, ka, NK_LATE ? nk_base + g : nk, 4 * g, exact, cand, r, sr, o, u, tmin, prev, pc RTOW_PROF_ARG);
     ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
     if (K_LDS && !NK_LATE) ka = nk[2];
-    group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(gb, kb, NK_LATE ? nk_base + g + 1 : nk + 1, 4 * g + 4, exact, cand, r, pre, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(gb, kb, NK_LATE ? nk_base + g + 1 : nk + 1, 4 * g + 4, exact, cand, r, sr, o, u, tmin, prev, pc RTOW_PROF_ARG);
     if (K_LDS && !NK_LATE) nk += 2;
   }
   cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
@@ -689,7 +693,7 @@ static __device__ __forceinline__ void scan_bundle(geom_ptr geom, ExactPtr exact
       f4v ka = {0, 0, 0, 0};
       const GroupRec grp = load_group<K_LDS, false>(geom, gg, ka, nullptr);
       if (K_LDS) ka = nk[gg];
-      group_test<true, -1, false, !K_LDS>(grp, ka, nk, 4 * gg, exact, cand, r, f2v{0.0f, 0.0f}, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
+      group_test<true, -1, false, !K_LDS>(grp, ka, nk, 4 * gg, exact, cand, r, SlabRay{f2v{0.0f, 0.0f}, f2v{0.0f, 0.0f}}, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
     }
   }
   cand_drain<true>(cand, exact, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
@@ -1102,9 +1106,9 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         RTOW_COUNT(14, 1);
         RTOW_STAMP(t_scan0);
         // the screen runs on the binary32 roundings of the ray; survivors get the binary64 test
-        // rmax (the largest radius in the binary32 table) sits behind the camera in the kernel arguments
+        // slab_inv_rmin sits behind the camera in the kernel arguments
         typedef const float __attribute__((address_space(4)))* karg_f32_ptr;
-        static_assert(offsetof(TraceParams, rmax) == sizeof(CameraParams64), "rmax follows the camera");
+        static_assert(offsetof(TraceParams, slab_inv_rmin) == sizeof(CameraParams64), "slab_inv_rmin follows the camera");
         if constexpr (SLAB_AXIS == kBundleTest) {
           // axis of the bundle: from the middle of the lens to the point the wave's first ray aims at (any axis is
           // valid - the spread of the rays is measured about it - this one sits in the middle of the lens)
@@ -1117,10 +1121,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
           if (X_LDS) scan_bundle<K_LDS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, ax, aw, pc RTOW_PROF_ARG);
           else scan_bundle<K_LDS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, ax, aw, pc RTOW_PROF_ARG);
         } else {
-          f2v pre = {0.0f, 0.0f};
-          if (SLAB_AXIS >= 0) pre = slab_operands<SLAB_AXIS < 0 ? 0 : SLAB_AXIS>(so, su, KARG(cmax), ((karg_f32_ptr)cf)[2 * 19]);
-          if (X_LDS) scan_regular<true, K_LDS, SLAB_AXIS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
-          else scan_regular<true, K_LDS, SLAB_AXIS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, pre RTOW_PROF_ARG);
+          SlabRay sr = {f2v{0.0f, 0.0f}, f2v{0.0f, 0.0f}};
+          if (SLAB_AXIS >= 0) sr = slab_operands<SLAB_AXIS < 0 ? 0 : SLAB_AXIS>(so, su, KARG(cmax), ((karg_f32_ptr)cf)[2 * 19]);
+          if (X_LDS) scan_regular<true, K_LDS, SLAB_AXIS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, sr RTOW_PROF_ARG);
+          else scan_regular<true, K_LDS, SLAB_AXIS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, 0.0f, -1, pc, sr RTOW_PROF_ARG);
         }
         RTOW_STAMP(t_scan1);
       }
@@ -1214,8 +1218,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
       // all 64 lanes take part: lanes without a path offer no candidates but help with the exact tests
       if (X_LDS && exhausted && (uint32_t)__popcll(__ballot(alive)) <= kSparseLanes)
         scan_sparse(exact_lds, nk_lds, cand, KARG(n_geom_pad), KARG(cmax), alive, o, u, tmin, prev, pc RTOW_PROF_ARG);
-      else if (X_LDS) scan_regular<false, K_LDS, -1>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
-      else scan_regular<false, K_LDS, -1>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), alive, o, u, tmin, prev, pc, f2v{0.0f, 0.0f} RTOW_PROF_ARG);
+      else if (X_LDS) scan_regular<false, K_LDS, -1>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), alive, o, u, tmin, prev, pc, SlabRay{f2v{0.0f, 0.0f}, f2v{0.0f, 0.0f}} RTOW_PROF_ARG);
+      else scan_regular<false, K_LDS, -1>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), alive, o, u, tmin, prev, pc, SlabRay{f2v{0.0f, 0.0f}, f2v{0.0f, 0.0f}} RTOW_PROF_ARG);
       RTOW_STAMP(t_scan1);
       // A path that ends adds its radiance to its pixel right away, through the wave's cache of pixel sums
       // (paths that end absorbed or at the depth limit are black and add nothing).

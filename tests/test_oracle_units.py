@@ -316,12 +316,14 @@ def test_mirror_scatter_tracks_the_fp64_scatter(oracle):
 
 
 def test_slab_test_of_camera_rays_is_conservative():
-    """The renderer puts a three-FMA slab test in front of the sphere screen for camera rays: component k of
-    (c - o) x u, evaluated in binary32 on rounded operands, against |r| with the slack delta (2 rmax + delta),
-    delta = 2^-14 (|o|_1 + cmax).  Restated here in numpy (binary32 operations, fused where the kernel fuses) and
-    held against the exact geometry in binary64: no sphere whose line distance is within its radius may fail,
-    along any axis, for near and far cameras and small and large scenes; the worst case must leave most of the
-    slack unused."""
+    """The renderer puts a slab test in front of the sphere screen for camera rays: component k of (c - o) x u,
+    evaluated in binary32 on rounded operands with two FMAs per (ray, sphere) pair, and the smallest |value| of a
+    group of four spheres against ONE radius per group, the largest |r| of the four (raised to 2^-8 of the scene's
+    extent).  The slack for rounding, delta = 2^-14 (|o|_1 + cmax), enters as a scale of the ray's operands,
+    s = 1 / (1 + delta / rmin) with rmin the smallest group radius.  Restated here in numpy (binary32 operations, fused
+    where the kernel fuses) and held against the exact geometry in binary64: no sphere whose line distance is within
+    its radius may fail, along any axis, for near and far cameras and small and large scenes, equal and mixed radii
+    within a group; the worst case must leave most of the slack unused."""
     import numpy as np
     f32 = np.float32
 
@@ -330,12 +332,12 @@ def test_slab_test_of_camera_rays_is_conservative():
 
     rng = np.random.default_rng(9)
     worst = 0.0
-    for spread, cam_dist, rad in ((11.0, 14.0, 0.2), (11.0, 300.0, 0.2), (200.0, 50.0, 3.0), (1.0, 2.0, 0.05), (30.0, 5000.0, 20.0)):
+    for spread, cam_dist, rad, mixed in ((11.0, 14.0, 0.2, False), (11.0, 300.0, 0.2, True), (200.0, 50.0, 3.0, True), (1.0, 2.0, 0.05, False),
+                                         (30.0, 5000.0, 20.0, True), (11.0, 14.0, 0.0005, True)):
         n = 400
         c64 = np.column_stack([rng.uniform(-spread, spread, n), rng.uniform(0, 0.3 * spread, n), rng.uniform(-spread, spread, n)])
-        r64 = rad * np.exp(rng.uniform(-1, 1, n)) * rng.choice([1.0, -1.0], n)
+        r64 = rad * (np.exp(rng.uniform(-1, 1, n)) if mixed else np.ones(n)) * rng.choice([1.0, -1.0], n)
         cmax = f32((np.linalg.norm(c64.astype(f32).astype(np.float64), axis=1) + np.abs(r64)).max())
-        rmax = f32(np.abs(r64).max())
         m = 3000
         o64 = rng.normal(0, 1, (m, 3)); o64 *= cam_dist / np.linalg.norm(o64, axis=1, keepdims=True)
         target = c64[rng.integers(0, n, m)] + rng.normal(0, 1, (m, 3)) * np.abs(r64).mean()   # aim near spheres: many grazing rays
@@ -350,17 +352,25 @@ def test_slab_test_of_camera_rays_is_conservative():
         inv = (f32(1.0) / np.sqrt(fma32(d[:, 2], d[:, 2], fma32(d[:, 1], d[:, 1], d[:, 0] * d[:, 0])))).astype(f32)
         u = (d * inv[:, None]).astype(f32)
         c = c64.astype(f32); r = r64.astype(f32)
+        # the host's table: one radius per group of four, floored, and the reciprocal of the smallest
+        rg = np.maximum(np.abs(r).reshape(-1, 4).max(axis=1), cmax * f32(2.0 ** -8)).astype(f32)
+        inv_rmin = f32(1.0) / rg.min()
         delta = ((np.abs(o[:, 0]) + np.abs(o[:, 1]) + np.abs(o[:, 2]) + cmax) * f32(2.0 ** -14)).astype(f32)
-        slack = (delta * fma32(np.full(m, 2.0, f32), np.full(m, rmax, f32), delta)).astype(f32)
+        # hardware reciprocal: within one ulp of the exact one; the kernel backs off by 2^-20
+        s_scale = ((f32(1.0) / fma32(delta, np.full(m, inv_rmin, f32), np.full(m, 1.0, f32))).astype(f32) * f32(1.0 - 2.0 ** -20)).astype(f32)
         for axis in range(3):
             i, j = (axis + 1) % 3, (axis + 2) % 3
-            mm = fma32(o[:, j], u[:, i], -(o[:, i] * u[:, j]).astype(f32))
-            t = fma32(np.broadcast_to(c[None, :, j], (m, n)), np.broadcast_to(-u[:, None, i], (m, n)), np.broadcast_to(mm[:, None], (m, n)))
-            v = fma32(np.broadcast_to(c[None, :, i], (m, n)), np.broadcast_to(u[:, None, j], (m, n)), t)
-            g = fma32(v, v, np.broadcast_to(-(r * r).astype(f32)[None, :], (m, n)))
-            passes = g <= slack[:, None]
+            sui = (s_scale * u[:, i]).astype(f32); suj = (s_scale * u[:, j]).astype(f32)
+            mm = (s_scale * fma32(o[:, j], u[:, i], -(o[:, i] * u[:, j]).astype(f32))).astype(f32)
+            t = fma32(np.broadcast_to(c[None, :, j], (m, n)), np.broadcast_to(-sui[:, None], (m, n)), np.broadcast_to(mm[:, None], (m, n)))
+            v = np.abs(fma32(np.broadcast_to(c[None, :, i], (m, n)), np.broadcast_to(suj[:, None], (m, n)), t))
+            group_min = v.reshape(m, -1, 4).min(axis=2)
+            passes = np.repeat(group_min <= rg[None, :], 4, axis=1)   # the whole group goes on to the screen or none of it
             assert passes[hit].all(), (spread, cam_dist, axis, int((~passes[hit]).sum()))
-            used = (g[hit] / np.broadcast_to(slack[:, None], (m, n))[hit]).max()   # > 0 only where rounding ate into the slack
-            worst = max(worst, float(used))
-        assert hit.sum() > 2000
-    assert worst < 0.1, worst   # the slack is at least ten times what rounding takes
+            # how much of the slack rounding used: the value the test saw against the exact distance (which bounds the
+            # component) scaled the same way
+            over = (v[hit] - (np.broadcast_to(s_scale[:, None].astype(np.float64), (m, n)) * dist)[hit])
+            room = (np.broadcast_to((s_scale.astype(np.float64) * delta.astype(np.float64))[:, None], (m, n)))[hit]
+            worst = max(worst, float((over / room).max()))
+        assert hit.sum() > 1000
+    assert worst < 0.1, worst   # rounding takes less than a tenth of the slack the scale provides
