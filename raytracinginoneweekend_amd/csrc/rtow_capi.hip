@@ -381,7 +381,7 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   // The slab test of the camera rays (rtow_kernels.hip, pair_slab) compares a ray's distance to each of a group's
   // four centres with ONE radius per group: the largest |r| among the group's spheres (a group without a sphere of the
   // binary32 table gets -1 and never passes).  Tables that fit LDS take -k from there, which leaves the last four
-  // floats of a group record free: the first of them carries that radius; larger tables keep it in an array of its own.
+  // floats of a group record free: the last of them carries that radius; larger tables keep it in an array of its own.
   const bool slab_table = n_pad <= rtow::kMaxSpheresKInLds;
   const int n_groups_alloc = n_alloc / 4;
   std::vector<float> group_radius((size_t)n_groups_alloc, -1.0f);
@@ -428,7 +428,7 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
       slab_rmin = std::min(slab_rmin, rg);
     }
     if (slab_table)
-      for (int k = 0; k < 4; ++k) geom[(size_t)g * 16 + 12 + (size_t)k] = k == 0 ? rg : 0.0f;
+      for (int k = 0; k < 4; ++k) geom[(size_t)g * 16 + 12 + (size_t)k] = k == 3 ? rg : 0.0f;
   }
   const std::vector<float>& slab = group_radius;
   HIP_TRY(c->geom64.reserve(sizeof(double4) * geom64.size()));

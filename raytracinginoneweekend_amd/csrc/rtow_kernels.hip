@@ -462,7 +462,10 @@ static __device__ __forceinline__ GroupRec load_group(geom_ptr geom, int g, f4v&
     typedef const f4v __attribute__((address_space(4)))* p4;
     r.a = *(p8)(geom + g);
     r.b = *((p4)(geom + g) + 2);
-    if (SLAB) r.rg = *((slab_ptr)(geom + g) + 12);   // tables whose -k sits in LDS keep the slab test's radius here
+    // tables whose -k sits in LDS keep the slab test's radius in the LAST float of the record: next to the centres
+    // the compiler would fetch it with them as one eight-dword load, whose unused registers it then takes for
+    // temporaries - and every write to one of those waits for the load
+    if (SLAB) r.rg = *((slab_ptr)(geom + g) + 15);
   } else {
     const f16v v = geom[g];
     r.a = v.lo;
@@ -602,6 +605,29 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   // (NK_LATE: the address of a group's -k is formed from the group index where it is needed - one group in eleven -
   // instead of being carried along in a register that every trip has to advance)
   const nk_lds_ptr nk_base = (nk_lds_ptr)nk_lds;
+#ifndef RTOW_SLAB_LOADS_UNORDERED
+  if (SLAB) {
+    // A wait for scalar loads is a wait for ALL of them (they return out of order), so a group requested just before
+    // the wait for its predecessor is waited for at once, and with seven instructions per group there is little
+    // other work to hide that behind.  The empty asm statements read a register of the group about to be used: the
+    // wait lands there, and the next group is requested only after it - every request then has one group's worth of
+    // work (of this wave and of the four others of the SIMD) to arrive in.
+    for (int g = 0; g < n_groups; g += 2) {
+      asm volatile("" : : "s"(ga.a.s0));
+      __builtin_amdgcn_sched_barrier(0);
+      const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
+      __builtin_amdgcn_sched_barrier(0);
+      group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(ga, ka, NK_LATE ? nk_base + g : nk, 4 * g, exact, cand, r, sr, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      asm volatile("" : : "s"(gb.a.s0));
+      __builtin_amdgcn_sched_barrier(0);
+      ga = load_group<K_LDS, SLAB>(geom, g + 2, ka, slab);
+      __builtin_amdgcn_sched_barrier(0);
+      group_test<PRIMARY, AXIS, NK_LATE, !K_LDS>(gb, kb, NK_LATE ? nk_base + g + 1 : nk + 1, 4 * g + 4, exact, cand, r, sr, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    }
+    cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    return;
+  }
+#endif
   for (int g = 0; g < n_groups; g += 2) {
     const GroupRec gb = load_group<K_LDS, SLAB>(geom, g + 1, kb, slab);
     if (K_LDS && !NK_LATE) kb = nk[1];
