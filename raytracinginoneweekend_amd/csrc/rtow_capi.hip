@@ -157,6 +157,12 @@ struct rtow_ctx {
   float cmax = 0.0f;
   float slab_inv_rmin = 1.0f;                 // 1 / (smallest group radius of the slab test), see set_scene_impl
   int slab_axis = 1;                          // axis of the camera rays' slab test, chosen from the camera
+  // interval test of the camera rays (refresh_spans): tables derived from scene AND camera
+  DevBuf span_mid, span_half;
+  std::vector<double4> host_geom64;           // the scene as given (centre, radius), kept for refresh_spans
+  std::vector<uint8_t> host_regular;          // per list entry: 1 = in the binary32 table (|radius| < kBigRadius)
+  std::vector<float> host_span_mid, host_span_half;   // staging of the uploads (must outlive the copies)
+  bool spans_valid = false;                   // the tables match the current scene and camera, and the camera is a regular one
   rtow::CameraParams64 cam;
 
   // per-render workspace
@@ -271,7 +277,7 @@ int rtow_destroy(rtow_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release_scratch(c);
-  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom_slab.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
+  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom_slab.release(); c->span_mid.release(); c->span_half.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release(); c->ray_in.release(); c->ray_out.release(); c->gather.release();
   if (c->gather_host) (void)hipHostFree(c->gather_host);
@@ -287,6 +293,91 @@ int rtow_destroy(rtow_ctx* c) {
 }
 
 }  // extern "C"
+
+// Interval test of the camera rays (rtow_kernels.hip, scan_interval).  A camera ray is the line from a point of the
+// lens disk to the point P(s, t) = llc + s hor + t ver of the focus plane (camera.nim:34-39).  Seen along the camera's
+// up axis v - dropping that coordinate - lens and focus plane are two parallel lines a distance f apart, the sphere is
+// a circle of the same radius, and a ray that meets the sphere projects to a line that meets the circle.  For a lens
+// point x_l and a circle (X, Z, rho) wholly in front of the lens line (Z > rho), the lines through x_l that meet the
+// circle reach the focus line between x_l + f m_lo and x_l + f m_hi,
+//     m = (A Z -+ rho sqrt(A^2 + Z^2 - rho^2)) / (Z^2 - rho^2),   A = X - x_l,
+// (the two tangents); m_hi is convex and m_lo concave in x_l, so over the lens |x_l| <= R the extremes sit at its two
+// ends.  That gives, per sphere, a range [s_lo, s_hi] of the image coordinate s outside which no camera ray can meet
+// it; a sphere wholly behind the lens line is met by no ray, one that reaches across it gets the whole axis.  The
+// kernel compares |s - middle| of every (ray, sphere) pair with the largest half width of the sphere's group of four:
+// one packed subtraction per two spheres.  Ranges are widened by 2^-19 (|s_lo| + |s_hi| + 2): the subtraction runs in
+// binary32 on roundings of s and of the middle.  Everything here is evaluated in binary64 on the scene as given,
+// which is what the binary64 test that decides a camera ray's hit sees.
+// The construction needs the camera the reference builds (camera.nim:12-31): u, v orthonormal, hor and ver along
+// them, the focus plane perpendicular to u x v and in front of the lens.  Any other set of eight vectors the ABI
+// accepts leaves spans_valid false, and the camera rays see the slab test instead.
+static int refresh_spans(rtow_ctx* c) {
+  c->spans_valid = false;
+  if (!c->have_scene || !c->have_camera) return RTOW_OK;
+  const rtow::CameraParams64& cam = c->cam;
+  auto dot = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  const double hu = std::sqrt(dot(cam.hor, cam.hor)), hv = std::sqrt(dot(cam.ver, cam.ver));
+  const double w[3] = {cam.u[1] * cam.v[2] - cam.u[2] * cam.v[1], cam.u[2] * cam.v[0] - cam.u[0] * cam.v[2],
+                       cam.u[0] * cam.v[1] - cam.u[1] * cam.v[0]};   // u x v: the direction the camera looks away from
+  double F[3];
+  for (int k = 0; k < 3; ++k) F[k] = cam.origin[k] - 0.5 * cam.hor[k] - 0.5 * cam.ver[k] - cam.llc[k];   // = f w
+  const double f = dot(F, w);
+  const double R = cam.lens_radius;
+  bool regular = std::isfinite(hu) && std::isfinite(hv) && hu > 0.0 && hv > 0.0 && std::isfinite(f) && f > 0.0 &&
+                 std::isfinite(R) && R >= 0.0 && std::fabs(dot(cam.u, cam.u) - 1.0) < 1e-9 &&
+                 std::fabs(dot(cam.v, cam.v) - 1.0) < 1e-9 && std::fabs(dot(cam.u, cam.v)) < 1e-9;
+  for (int k = 0; k < 3 && regular; ++k)
+    regular = std::fabs(cam.hor[k] - hu * cam.u[k]) <= 1e-9 * hu && std::fabs(cam.ver[k] - hv * cam.v[k]) <= 1e-9 * hv &&
+              std::fabs(F[k] - f * w[k]) <= 1e-9 * (f + hu + hv) && std::isfinite(cam.origin[k]);
+  if (!regular) return RTOW_OK;
+
+  const int n = c->n_spheres, n_alloc = c->n_geom_pad + 8;
+  const float kNever = 1e30f;
+  c->host_span_mid.assign((size_t)n_alloc, kNever);
+  c->host_span_half.assign((size_t)(n_alloc / 4), -1.0f);
+  const double Rl = R * (1.0 + 1e-9);
+  for (int j = 0; j < n; ++j) {
+    if (!c->host_regular[(size_t)j]) continue;   // the |radius| >= kBigRadius spheres are tested by every ray anyway
+    const double4 sp = c->host_geom64[(size_t)j];
+    const double rel[3] = {sp.x - cam.origin[0], sp.y - cam.origin[1], sp.z - cam.origin[2]};
+    const double X = dot(rel, cam.u), Z = -dot(rel, w);
+    // The camera's vectors may be off the ideal frame by 1e-9 of their lengths (the check above), and the ray and this
+    // arithmetic round in binary64: lens and focus points then sit within 1e-9 (hu + hv + f + R) of where the
+    // construction puts them, which moves a line by up to (1 + Z / f) times that at the sphere's depth.
+    const double rho = std::fabs(sp.w) * (1.0 + 1e-9) + 4e-9 * (hu + hv + f + Rl + std::fabs(X) + std::fabs(Z)) * (1.0 + std::fabs(Z) / f);
+    float mid, half;
+    if (Z < -rho) continue;                      // wholly behind the lens line: never
+    if (!(Z > rho * (1.0 + 1e-6))) {             // reaches across the lens line: any s
+      mid = 0.0f; half = INFINITY;
+    } else {
+      const double k = Z * Z - rho * rho;
+      double s_lo = INFINITY, s_hi = -INFINITY;
+      for (int e = 0; e < 2; ++e) {
+        const double xl = e ? Rl : -Rl, A = X - xl, root = rho * std::sqrt(A * A + k);
+        s_lo = std::min(s_lo, (xl + f * (A * Z - root) / k) / hu + 0.5);
+        s_hi = std::max(s_hi, (xl + f * (A * Z + root) / k) / hu + 0.5);
+      }
+      if (!std::isfinite(s_lo) || !std::isfinite(s_hi)) { mid = 0.0f; half = INFINITY; }
+      else {
+        const double pad = 0x1p-19 * (std::fabs(s_lo) + std::fabs(s_hi) + 2.0);
+        mid = (float)(0.5 * (s_lo + s_hi));
+        // half width against the ROUNDED middle, rounded up
+        half = std::nextafter((float)(std::max(s_hi - (double)mid, (double)mid - s_lo) + pad), INFINITY);
+        if (!std::isfinite(mid) || std::fabs(mid) >= kNever) { mid = 0.0f; half = INFINITY; }
+      }
+    }
+    c->host_span_mid[(size_t)j] = mid;
+    float& hg = c->host_span_half[(size_t)(j / 4)];
+    if (half > hg) hg = half;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // a render may still be reading the old tables
+  HIP_TRY(hipMemcpyAsync(c->span_mid.p, c->host_span_mid.data(), sizeof(float) * c->host_span_mid.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->span_half.p, c->host_span_half.data(), sizeof(float) * c->host_span_half.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->spans_valid = true;
+  return RTOW_OK;
+}
 
 template <typename T>
 static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T* cz, const T* radius, const uint8_t* kind,
@@ -436,6 +527,8 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
+  HIP_TRY(c->span_mid.reserve(sizeof(float) * (size_t)n_alloc));        // filled by refresh_spans once a camera is known
+  HIP_TRY(c->span_half.reserve(sizeof(float) * (size_t)n_groups_alloc));
   HIP_TRY(c->geom_slab.reserve(sizeof(float) * slab.size()));
   HIP_TRY(hipMemcpyAsync(c->geom_slab.p, slab.data(), sizeof(float) * slab.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
@@ -460,7 +553,10 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   c->have_scene = true;
   c->samples_done = 0;              // accumulated samples belong to the previous scene: no pass may continue them
   c->last_row_list_valid = false;
-  return RTOW_OK;
+  c->host_geom64.assign(geom64.begin(), geom64.begin() + n);
+  c->host_regular.assign((size_t)n, 0);
+  for (int j = 0; j < n; ++j) c->host_regular[(size_t)j] = std::fabs((float)radius[j]) < rtow::kBigRadius ? 1 : 0;
+  return refresh_spans(c);
 }
 
 extern "C" {
@@ -482,7 +578,7 @@ static int set_camera_f64(rtow_ctx* c, const rtow_camera_f64& cam) {
   c->have_camera = true;
   c->samples_done = 0;              // accumulated samples belong to the previous camera: no pass may continue them
   c->last_row_list_valid = false;
-  return RTOW_OK;
+  return refresh_spans(c);
 }
 
 int rtow_set_camera_f64(rtow_ctx* c, const rtow_camera_f64* cam) {
@@ -520,6 +616,7 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   p.geom = (const float*)c->geom.p; p.geom_exact = (const float4*)c->geom_rr.p; p.geom_nk = (const float*)c->geom_nk.p; p.n_geom_pad = c->n_geom_pad;
   p.geom64 = (const double4*)c->geom64.p; p.n_list = c->n_spheres;
   p.geom_slab = (const float*)c->geom_slab.p;
+  p.span_mid = (const float*)c->span_mid.p; p.span_half = (const float*)c->span_half.p;
   p.cmax = c->cmax;
   p.slab_inv_rmin = c->slab_inv_rmin;
   p.pad_ = 0.0f;
@@ -557,16 +654,22 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   HIP_TRY(hipMemsetAsync(t.counters, 0, kCounterBytes, c->stream));
   if (first_sample == 0 && n_pixels) HIP_TRY(hipMemsetAsync(t.accum, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  // What the camera rays of a wave see before the filter (rtow_kernels.hip): by default the slab test along the axis
-  // the view direction is most perpendicular to (pair_slab) - every ray still tests every sphere itself.  The image
-  // does not depend on the choice; for measurements and tests: RTOW_NO_SLAB_TEST = nothing in front of the filter,
-  // RTOW_SLAB_AXIS=0|1|2 = the slab test along a given axis, RTOW_CAMERA_SCREEN=bundle = the bundle test (scan_bundle:
-  // the table against the wave's 64 rays as a whole).  The bundle test decides about a sphere once per wave instead
-  // of once per ray, which is culling by ray packets rather than brute force: it is an option, never the default.
-  int slab_axis = c->slab_axis;
+  // What the camera rays of a wave see before the filter (rtow_kernels.hip): by default the interval test
+  // (scan_interval: the ray's image coordinate against the range in which the sphere can be met; tables from
+  // refresh_spans), or, for a camera that construction does not cover, the slab test along the axis the view direction
+  // is most perpendicular to (pair_slab).  In both every ray still tests every sphere itself.  The image does not
+  // depend on the choice; for measurements and tests: RTOW_NO_SLAB_TEST = nothing in front of the filter,
+  // RTOW_CAMERA_SCREEN=slab = the slab test, RTOW_SLAB_AXIS=0|1|2 = the slab test along a given axis,
+  // RTOW_CAMERA_SCREEN=bundle = the bundle test (scan_bundle: the table against the wave's 64 rays as a whole).  The
+  // bundle test decides about a sphere once per wave instead of once per ray, which is culling by ray packets rather
+  // than brute force: it is an option, never the default.
+  int slab_axis = c->spans_valid ? rtow::kIntervalTest : c->slab_axis;
   if (getenv("RTOW_NO_SLAB_TEST")) slab_axis = -1;
   else if (const char* e = getenv("RTOW_SLAB_AXIS")) { const int v = atoi(e); if (v >= 0 && v <= 2) slab_axis = v; }
-  else if (const char* s = getenv("RTOW_CAMERA_SCREEN")) { if (!strcmp(s, "bundle")) slab_axis = rtow::kBundleTest; }
+  else if (const char* s = getenv("RTOW_CAMERA_SCREEN")) {
+    if (!strcmp(s, "bundle")) slab_axis = rtow::kBundleTest;
+    else if (!strcmp(s, "slab")) slab_axis = c->slab_axis;
+  }
   if (n_pixels) rtow::launch_trace(p, slab_axis, grid, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));

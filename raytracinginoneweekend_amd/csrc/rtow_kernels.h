@@ -23,6 +23,9 @@ struct TraceParams {
   const float4* geom_exact;  // (cx, cy, cz, r^2) per list entry, fetched per lane for the exact test
   const double4* geom64;     // (cx, cy, cz, r) per list entry in binary64: the exact test of primary rays
   const float* geom_slab;    // the slab test's radius per group of four (negative: never passes) for tables beyond kMaxSpheresKInLds entries
+  const float* span_mid;     // interval test of the camera rays: per list entry the middle of the range of the image coordinate s
+                             // in which a camera ray can meet the sphere (n_geom_pad + 8 values) ...
+  const float* span_half;    // ... and per group of four the largest half width of its four ranges (negative: never passes)
   int n_geom_pad;
   int n_list;                // spheres in the list (= entries of geom64 and shade)
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin
@@ -86,8 +89,9 @@ struct ScatterParams {
 void launch_scatter(const ScatterParams& p, hipStream_t stream);
 
 // slab_axis: what the camera rays see before the filter: the slab test along axis 0, 1 or 2 (see pair_slab), the
-// bundle test (kBundleTest; see scan_bundle), or -1 for nothing
+// bundle test (kBundleTest; see scan_bundle), the interval test (kIntervalTest; see scan_interval), or -1 for nothing
 constexpr int kBundleTest = 3;
+constexpr int kIntervalTest = 4;
 void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);

@@ -725,6 +725,65 @@ static __device__ __forceinline__ void scan_bundle(geom_ptr geom, ExactPtr exact
   cand_drain<true>(cand, exact, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
 }
 
+// Closest hit of the camera rays of a PRIMARY iteration behind the interval test.  For every sphere the host has
+// worked out, from scene and camera, the range of the image coordinate s - the first argument of getRay
+// (camera.nim:34), which runs across the image - outside which no camera ray can meet it, whatever its t and its point
+// on the lens (rtow_capi.hip, refresh_spans).  Every ray compares its own s with that range for every sphere of the
+// list, in list order: one packed subtraction per two spheres, |s - middle| of a group's four against the largest half
+// width among them (one scalar per group), five instructions per group where the filter takes seventeen.  Only the
+// groups in which some lane's ray passes fetch their centres and go through the filter and the exact tests, as in a
+// scan without any such test.  The test needs one number per ray and five per group; what it drops are spheres the
+// ray cannot meet, so hits, images and segment counts are those of the plain scan.
+typedef const f4v __attribute__((address_space(4)))* span_mid_ptr;
+typedef const float __attribute__((address_space(4)))* span_half_ptr;
+
+template <bool K_LDS, bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void interval_group(const f4v mid, const float half, const f2v sv, int g, geom_ptr geom,
+                                                      nk_lds_ptr nk, ExactPtr exact, CandList<SHORT>& cand, const ScanRay& r,
+                                                      f3 o, f3 u, const PrimaryCtx& pc RTOW_PROF_PARAM) {
+  f2v d0, d1;   // middle - s for two spheres at a time (the low half of sv for both)
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d0) : "s"(mid.xy), "v"(sv));
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d1) : "s"(mid.zw), "v"(sv));
+  if (__ballot(min_abs4(d0, d1) <= half) == 0) return;   // wave-uniform: no ray of the wave can meet any of the four
+  RTOW_COUNT(24, 1);
+  f4v ka = {0, 0, 0, 0};
+  const GroupRec grp = load_group<K_LDS, false>(geom, g, ka, nullptr);
+  if (K_LDS) ka = nk[g];
+  group_test<true, -1, false, !K_LDS>(grp, ka, nk, 4 * g, exact, cand, r, SlabRay{f2v{0.0f, 0.0f}, f2v{0.0f, 0.0f}}, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
+}
+
+template <bool K_LDS, bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void scan_interval(geom_ptr geom, ExactPtr exact, const f4v* nk_lds, CandList<SHORT>& cand,
+                                                     int n_groups, float cmax, bool live, f3 o, f3 u, float s,
+                                                     const PrimaryCtx& pc RTOW_PROF_PARAM) {
+  if (n_groups <= 0) return;
+  ScanRay r = scan_ray(o, u, cmax);
+  if (!live) { r.ozt.y = INFINITY; s = INFINITY; }   // an infinite distance passes no finite half width, an infinite filter threshold nothing
+  const f2v sv = {s, s};
+  const nk_lds_ptr nk = (nk_lds_ptr)nk_lds;
+  const span_mid_ptr mids = (span_mid_ptr)(uintptr_t)KARG(span_mid);
+  const span_half_ptr halves = (span_half_ptr)(uintptr_t)KARG(span_half);
+  f4v ma = mids[0];
+  float ha = halves[0];
+  // (the empty asm statements make the wait for a group's scalar loads land before the next group is requested: see
+  // the slab loop of scan_regular; the tables hold two all-padding groups behind the last one)
+  for (int g = 0; g < n_groups; g += 2) {
+    asm volatile("" : : "s"(ma.x));
+    __builtin_amdgcn_sched_barrier(0);
+    const f4v mb = mids[g + 1];
+    const float hb = halves[g + 1];
+    __builtin_amdgcn_sched_barrier(0);
+    interval_group<K_LDS>(ma, ha, sv, g, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+    asm volatile("" : : "s"(mb.x));
+    __builtin_amdgcn_sched_barrier(0);
+    ma = mids[g + 2];
+    ha = halves[g + 2];
+    __builtin_amdgcn_sched_barrier(0);
+    interval_group<K_LDS>(mb, hb, sv, g + 1, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+  }
+  cand_drain<true>(cand, exact, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
+}
+
 // The same closest-hit query for a wave that has only a few paths left (the end of a frame, when no
 // work is left to refill the idle lanes): instead of every lane walking the whole table for its own
 // ray, the rays are taken one at a time and the TABLE is spread over the 64 lanes - lane L screens
@@ -873,8 +932,8 @@ static_assert(kPoolFields >= 14, "the pool region also holds seven doubles per l
 // K_LDS: -k per sphere in LDS (tables up to kMaxSpheresKInLds entries).  X_LDS: the records of the
 // exact test (16 bytes per sphere) in LDS as well (tables up to kMaxSpheresExactInLds entries): a
 // round of exact tests then waits for LDS, not for L2, and the survivor list has 16-bit entries.
-// SLAB_AXIS: what camera rays see before the filter: the slab test along axis 0, 1 or 2, the bundle test
-// (kBundleTest, see scan_bundle), or nothing (-1: every ray screens every sphere itself).
+// SLAB_AXIS: what camera rays see before the filter: the slab test along axis 0, 1 or 2, the interval test
+// (kIntervalTest, see scan_interval), the bundle test (kBundleTest, see scan_bundle), or nothing (-1).
 template <bool K_LDS, bool X_LDS, int SLAB_AXIS>
 __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const TraceParams P) {
   // LDS: [4 waves][WaveLds::kTotal], then (K_LDS) -k per sphere, then (X_LDS) the exact-test records
@@ -1135,7 +1194,10 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         // slab_inv_rmin sits behind the camera in the kernel arguments
         typedef const float __attribute__((address_space(4)))* karg_f32_ptr;
         static_assert(offsetof(TraceParams, slab_inv_rmin) == sizeof(CameraParams64), "slab_inv_rmin follows the camera");
-        if constexpr (SLAB_AXIS == kBundleTest) {
+        if constexpr (SLAB_AXIS == kIntervalTest) {
+          if (X_LDS) scan_interval<K_LDS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, (float)cs, pc RTOW_PROF_ARG);
+          else scan_interval<K_LDS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, (float)cs, pc RTOW_PROF_ARG);
+        } else if constexpr (SLAB_AXIS == kBundleTest) {
           // axis of the bundle: from the middle of the lens to the point the wave's first ray aims at (any axis is
           // valid - the spread of the rays is measured about it - this one sits in the middle of the lens)
           const f3 ax = {(float)cf[0], (float)cf[1], (float)cf[2]};
@@ -1370,6 +1432,7 @@ void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStrea
     case 1: launch_trace_axis<1>(p, grid_blocks, stream); break;
     case 2: launch_trace_axis<2>(p, grid_blocks, stream); break;
     case kBundleTest: launch_trace_axis<kBundleTest>(p, grid_blocks, stream); break;
+    case kIntervalTest: launch_trace_axis<kIntervalTest>(p, grid_blocks, stream); break;
     default: launch_trace_axis<-1>(p, grid_blocks, stream); break;
   }
 }

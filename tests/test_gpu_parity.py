@@ -691,9 +691,12 @@ def test_table_sizes_around_the_lds_thresholds(oracle):
 
 
 def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
-    """Camera rays see a 3-FMA slab test before the 7-FMA screen, along the axis the host picks from the camera.
-    It may only drop spheres the ray misses: without it (RTOW_NO_SLAB_TEST, read at every launch) and along each
-    of the three axes (RTOW_SLAB_AXIS) hit ids, sums and segment counts are the same - on the book scene, with
+    """Camera rays see a cheap necessary condition per (ray, sphere) pair before the 7-FMA screen: by default the
+    interval test (the ray's image coordinate against the range in which the sphere can be met at all), for other
+    cameras and on request (RTOW_CAMERA_SCREEN=slab) the slab test along the axis the host picks from the camera.
+    Either may only drop spheres the ray misses: with the default, without any such test (RTOW_NO_SLAB_TEST, read at
+    every launch), with the slab test along each of the three axes (RTOW_SLAB_AXIS) and with the optional bundle test
+    hit ids, sums and segment counts are the same - on the book scene, with
     the camera looking straight down and straight up (a projection degenerates), from inside a glass sphere, on a
     vertical stack of spheres, on a table beyond the LDS sizes - and equal the mirror, which has no such test."""
     from raytracinginoneweekend_amd.basetypes import point, vec3
@@ -720,8 +723,8 @@ def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
             r.setCamera(initCamera(point(*cam["look_from"]), point(*cam["look_at"]), vec3(0, 1, 0), vfov=cam["vfov"],
                                    aspectRatio=W / H, aperture=cam["aperture"], focusDist=cam["focus"]))
             ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H, **cam), W, H, spp, depth, threads=16)
-            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}, {"RTOW_SLAB_AXIS": "0"}, {"RTOW_SLAB_AXIS": "1"}, {"RTOW_SLAB_AXIS": "2"},
-                        {"RTOW_CAMERA_SCREEN": "bundle"}):
+            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}, {"RTOW_CAMERA_SCREEN": "slab"}, {"RTOW_SLAB_AXIS": "0"}, {"RTOW_SLAB_AXIS": "1"},
+                        {"RTOW_SLAB_AXIS": "2"}, {"RTOW_CAMERA_SCREEN": "bundle"}):
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
@@ -729,6 +732,50 @@ def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
                     monkeypatch.delenv(k)
                 _check_bit_exact(got, ref)
                 assert r.stats()["ray_segments"] == ref[3], env
+
+
+def test_camera_the_interval_test_does_not_cover_falls_back_to_the_slab_test(oracle, monkeypatch):
+    """The interval test is built for the camera the reference constructs (camera.nim:12-31).  The ABI takes any eight
+    vectors: a sheared image plane (horizontal not along u), a scaled basis, a binary32 camera - for those the
+    library must use the slab test instead, and the image must be that of a render without any such test.  The
+    regular camera given as binary64 and as binary32 roundings of itself is checked against the mirror as well."""
+    R = _R()
+    from raytracinginoneweekend_amd import _lib
+    W, H, spp, depth = 96, 64, 5, 50
+    arr, n = oracle.random_scene()[:2]
+    with R.Renderer(0) as r:
+        r.setWorld(R.randomScene())
+        base = R.bookCamera(W / H)
+        variants = []
+        sheared = base.to_struct()
+        for k in range(3):
+            sheared.horizontal[k] += 0.2 * sheared.v[k]
+        variants.append(sheared)
+        scaled = base.to_struct()
+        for k in range(3):
+            scaled.u[k] *= 1.5
+        variants.append(scaled)
+        tilted = base.to_struct()          # focus plane not perpendicular to u x v
+        for k in range(3):
+            tilted.lower_left[k] += 0.3 * tilted.u[k]
+        variants.append(tilted)
+        for cam in variants:
+            r.setCamera(cam)
+            got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+            seg = r.stats()["ray_segments"]
+            monkeypatch.setenv("RTOW_NO_SLAB_TEST", "1")
+            plain = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+            monkeypatch.delenv("RTOW_NO_SLAB_TEST")
+            assert (got[0] == plain[0]).all() and (got[1] == plain[1]).all() and (got[2] == plain[2]).all()
+            assert r.stats()["ray_segments"] == seg
+        ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H), W, H, spp, depth, threads=16)
+        r.setCamera(base)
+        _check_bit_exact(r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True), ref)
+        r.setCamera(base.to_struct(binary32=True))   # u, v no longer of unit length to 1e-9: the slab test
+        got32 = r.renderRows(W, H, spp, depth, want_hit_id=True)
+        monkeypatch.setenv("RTOW_NO_SLAB_TEST", "1")
+        plain32 = r.renderRows(W, H, spp, depth, want_hit_id=True)
+        assert (got32[0] == plain32[0]).all() and (got32[2] == plain32[2]).all()
 
 
 def test_optional_bundle_test_of_camera_rays_changes_nothing(oracle, monkeypatch):

@@ -374,3 +374,77 @@ def test_slab_test_of_camera_rays_is_conservative():
             worst = max(worst, float((over / room).max()))
         assert hit.sum() > 1000
     assert worst < 0.1, worst   # rounding takes less than a tenth of the slack the scale provides
+
+
+def test_interval_test_of_camera_rays_is_conservative():
+    """The renderer's default screen for camera rays: per sphere a range [s_lo, s_hi] of the image coordinate s (the
+    first argument of getRay, camera.nim:34) outside which no camera ray can meet the sphere, worked out by the host
+    from scene and camera.  Seen along the camera's up axis the lens is a segment |x| <= R on one line, the focus plane
+    a parallel line a distance f away, the sphere a circle (X, Z, rho); the lines from a lens point through the focus
+    line that touch the circle are the two tangents, and over the lens the extremes sit at its ends.  Restated here in
+    numpy and held against the exact geometry of camera.nim:34-39 rays in binary64: for random look-at cameras (near,
+    far, inside the field, wide and closed lenses) and random spheres, every ray whose LINE passes within |r| of a
+    centre has its s inside that sphere's range (widened as the kernel's binary32 subtraction needs), spheres wholly
+    behind the lens are met by no forward ray, and a sphere that reaches across the lens plane gets the whole axis."""
+    import numpy as np
+    rng = np.random.default_rng(17)
+    f32 = np.float32
+    checked = inside = 0
+    for trial in range(40):
+        spread = rng.choice([3.0, 11.0, 60.0])
+        n = 300
+        c = np.column_stack([rng.uniform(-spread, spread, n), rng.uniform(-0.2 * spread, 0.4 * spread, n), rng.uniform(-spread, spread, n)])
+        r = rng.choice([0.05, 0.2, 1.0, 4.0], n) * np.exp(rng.uniform(-0.5, 0.5, n)) * rng.choice([1.0, -1.0], n)
+        look_from = rng.normal(0, 1, 3) * rng.choice([0.3, 1.0, 3.0]) * spread
+        look_at = rng.normal(0, 0.3, 3) * spread
+        vup = np.array([0.0, 1.0, 0.0]) if trial % 3 else rng.normal(0, 1, 3)
+        vfov, aspect = rng.uniform(10, 100), rng.choice([1.0, 1.5, 16 / 9])
+        focus = rng.uniform(0.3, 2.0) * np.linalg.norm(look_from - look_at)
+        R = rng.choice([0.0, 0.05, 0.5, 2.0])
+        # initCamera (camera.nim:12-31)
+        h = np.tan(np.radians(vfov) / 2)
+        w = (look_from - look_at) / np.linalg.norm(look_from - look_at)
+        u = np.cross(vup, w); u /= np.linalg.norm(u)
+        v = np.cross(w, u)
+        hor, ver = focus * aspect * 2 * h * u, focus * 2 * h * v
+        llc = look_from - hor / 2 - ver / 2 - focus * w
+        # the host's table
+        hu = np.linalg.norm(hor)
+        X, Z = (c - look_from) @ u, -((c - look_from) @ w)
+        rho = np.abs(r) * (1 + 1e-9) + 4e-9 * (hu + np.linalg.norm(ver) + focus + R + np.abs(X) + np.abs(Z)) * (1 + np.abs(Z) / focus)
+        never = Z < -rho
+        always = ~never & ~(Z > rho * (1 + 1e-6))
+        k = Z * Z - rho * rho
+        with np.errstate(invalid="ignore", divide="ignore"):
+            lo, hi = np.full(n, np.inf), np.full(n, -np.inf)
+            for xl in (-R * (1 + 1e-9), R * (1 + 1e-9)):
+                A = X - xl
+                root = rho * np.sqrt(A * A + k)
+                lo = np.minimum(lo, (xl + focus * (A * Z - root) / k) / hu + 0.5)
+                hi = np.maximum(hi, (xl + focus * (A * Z + root) / k) / hu + 0.5)
+        pad = 2.0 ** -19 * (np.abs(lo) + np.abs(hi) + 2)
+        mid = (0.5 * (lo + hi)).astype(f32)
+        half = (np.maximum(hi - mid.astype(np.float64), mid.astype(np.float64) - lo) + pad).astype(f32)
+        half = np.nextafter(half, f32(np.inf))
+        # rays of getRay (camera.nim:34-39): lens point, focus-plane point; s and t a little beyond [0, 1] as the jitter allows
+        m = 4000
+        s, t = rng.uniform(-0.01, 1.01, m), rng.uniform(-0.01, 1.01, m)
+        ang, rad = rng.uniform(0, 2 * np.pi, m), np.sqrt(rng.uniform(0, 1, m))
+        rd = R * np.column_stack([rad * np.cos(ang), rad * np.sin(ang)])
+        off = rd[:, :1] * u[None, :] + rd[:, 1:] * v[None, :]
+        o = look_from[None, :] + off
+        d = llc[None, :] + s[:, None] * hor[None, :] + t[:, None] * ver[None, :] - look_from[None, :] - off
+        dn = d / np.linalg.norm(d, axis=1, keepdims=True)
+        oc = c[None, :, :] - o[:, None, :]
+        along = np.einsum("mnk,mk->mn", oc, dn)
+        dist = np.linalg.norm(oc - along[:, :, None] * dn[:, None, :], axis=2)
+        meets = dist <= np.abs(r)[None, :]                      # the ray's LINE meets the sphere
+        with np.errstate(invalid="ignore"):                     # ... at a point in front of the ray's origin (the far root)
+            forward = meets & (along + np.sqrt(np.maximum(np.abs(r)[None, :] ** 2 - dist ** 2, 0.0)) > 0)
+        # the kernel's test in binary32
+        passes = np.abs(mid[None, :] - s.astype(f32)[:, None]) <= half[None, :]
+        passes = np.where(always[None, :], True, np.where(never[None, :], False, passes))
+        assert passes[forward].all(), (trial, int((~passes[forward]).sum()))
+        assert not forward[:, never].any()
+        checked += int(forward.sum()); inside += int(always.sum())
+    assert checked > 20000 and inside > 50
