@@ -158,10 +158,10 @@ struct rtow_ctx {
   float slab_inv_rmin = 1.0f;                 // 1 / (smallest group radius of the slab test), see set_scene_impl
   int slab_axis = 1;                          // axis of the camera rays' slab test, chosen from the camera
   // interval test of the camera rays (refresh_spans): tables derived from scene AND camera
-  DevBuf span_mid, span_half;
+  DevBuf span_mid, span_half;                 // [0]: ranges of s (across the image), [1]: ranges of t (up the image), back to back
   std::vector<double4> host_geom64;           // the scene as given (centre, radius), kept for refresh_spans
   std::vector<uint8_t> host_regular;          // per list entry: 1 = in the binary32 table (|radius| < kBigRadius)
-  std::vector<float> host_span_mid, host_span_half;   // staging of the uploads (must outlive the copies)
+  std::vector<float> host_span_mid, host_span_half;   // staging of the uploads (must outlive the copies); s ranges, then t ranges
   bool spans_valid = false;                   // the tables match the current scene and camera, and the camera is a regular one
   rtow::CameraParams64 cam;
 
@@ -306,8 +306,9 @@ int rtow_destroy(rtow_ctx* c) {
 // it; a sphere wholly behind the lens line is met by no ray, one that reaches across it gets the whole axis.  The
 // kernel compares |s - middle| of every (ray, sphere) pair with the largest half width of the sphere's group of four:
 // one packed subtraction per two spheres.  Ranges are widened by 2^-19 (|s_lo| + |s_hi| + 2): the subtraction runs in
-// binary32 on roundings of s and of the middle.  Everything here is evaluated in binary64 on the scene as given,
-// which is what the binary64 test that decides a camera ray's hit sees.
+// binary32 on roundings of s and of the middle.  The same construction with u in the place of v bounds t, the
+// coordinate up the image: groups that pass for s are tested for t before they go on.  Everything here is evaluated
+// in binary64 on the scene as given, which is what the binary64 test that decides a camera ray's hit sees.
 // The construction needs the camera the reference builds (camera.nim:12-31): u, v orthonormal, hor and ver along
 // them, the focus plane perpendicular to u x v and in front of the lens.  Any other set of eight vectors the ABI
 // accepts leaves spans_valid false, and the camera rays see the slab test instead.
@@ -333,42 +334,48 @@ static int refresh_spans(rtow_ctx* c) {
 
   const int n = c->n_spheres, n_alloc = c->n_geom_pad + 8;
   const float kNever = 1e30f;
-  c->host_span_mid.assign((size_t)n_alloc, kNever);
-  c->host_span_half.assign((size_t)(n_alloc / 4), -1.0f);
+  // the same construction along the image's other axis (drop u instead of v) bounds the second argument of getRay, t
+  c->host_span_mid.assign((size_t)n_alloc * 2, kNever);
+  c->host_span_half.assign((size_t)(n_alloc / 4) * 2, -1.0f);
   const double Rl = R * (1.0 + 1e-9);
-  for (int j = 0; j < n; ++j) {
-    if (!c->host_regular[(size_t)j]) continue;   // the |radius| >= kBigRadius spheres are tested by every ray anyway
-    const double4 sp = c->host_geom64[(size_t)j];
-    const double rel[3] = {sp.x - cam.origin[0], sp.y - cam.origin[1], sp.z - cam.origin[2]};
-    const double X = dot(rel, cam.u), Z = -dot(rel, w);
-    // The camera's vectors may be off the ideal frame by 1e-9 of their lengths (the check above), and the ray and this
-    // arithmetic round in binary64: lens and focus points then sit within 1e-9 (hu + hv + f + R) of where the
-    // construction puts them, which moves a line by up to (1 + Z / f) times that at the sphere's depth.
-    const double rho = std::fabs(sp.w) * (1.0 + 1e-9) + 4e-9 * (hu + hv + f + Rl + std::fabs(X) + std::fabs(Z)) * (1.0 + std::fabs(Z) / f);
-    float mid, half;
-    if (Z < -rho) continue;                      // wholly behind the lens line: never
-    if (!(Z > rho * (1.0 + 1e-6))) {             // reaches across the lens line: any s
-      mid = 0.0f; half = INFINITY;
-    } else {
-      const double k = Z * Z - rho * rho;
-      double s_lo = INFINITY, s_hi = -INFINITY;
-      for (int e = 0; e < 2; ++e) {
-        const double xl = e ? Rl : -Rl, A = X - xl, root = rho * std::sqrt(A * A + k);
-        s_lo = std::min(s_lo, (xl + f * (A * Z - root) / k) / hu + 0.5);
-        s_hi = std::max(s_hi, (xl + f * (A * Z + root) / k) / hu + 0.5);
+  for (int axis = 0; axis < 2; ++axis) {
+    const double* across = axis == 0 ? cam.u : cam.v;   // the image axis the range is measured along
+    const double extent = axis == 0 ? hu : hv;         // length of the focus plane's edge along it
+    float* const mids = c->host_span_mid.data() + (size_t)axis * (size_t)n_alloc;
+    float* const halves = c->host_span_half.data() + (size_t)axis * (size_t)(n_alloc / 4);
+    for (int j = 0; j < n; ++j) {
+      if (!c->host_regular[(size_t)j]) continue;   // the |radius| >= kBigRadius spheres are tested by every ray anyway
+      const double4 sp = c->host_geom64[(size_t)j];
+      const double rel[3] = {sp.x - cam.origin[0], sp.y - cam.origin[1], sp.z - cam.origin[2]};
+      const double X = dot(rel, across), Z = -dot(rel, w);
+      // The camera's vectors may be off the ideal frame by 1e-9 of their lengths (the check above), and the ray and this
+      // arithmetic round in binary64: lens and focus points then sit within 1e-9 (hu + hv + f + R) of where the
+      // construction puts them, which moves a line by up to (1 + Z / f) times that at the sphere's depth.
+      const double rho = std::fabs(sp.w) * (1.0 + 1e-9) + 4e-9 * (hu + hv + f + Rl + std::fabs(X) + std::fabs(Z)) * (1.0 + std::fabs(Z) / f);
+      float mid, half;
+      if (Z < -rho) continue;                      // wholly behind the lens line: never
+      if (!(Z > rho * (1.0 + 1e-6))) {             // reaches across the lens line: any value
+        mid = 0.0f; half = INFINITY;
+      } else {
+        const double k = Z * Z - rho * rho;
+        double s_lo = INFINITY, s_hi = -INFINITY;
+        for (int e = 0; e < 2; ++e) {
+          const double xl = e ? Rl : -Rl, A = X - xl, root = rho * std::sqrt(A * A + k);
+          s_lo = std::min(s_lo, (xl + f * (A * Z - root) / k) / extent + 0.5);
+          s_hi = std::max(s_hi, (xl + f * (A * Z + root) / k) / extent + 0.5);
+        }
+        if (!std::isfinite(s_lo) || !std::isfinite(s_hi)) { mid = 0.0f; half = INFINITY; }
+        else {
+          const double pad = 0x1p-19 * (std::fabs(s_lo) + std::fabs(s_hi) + 2.0);
+          mid = (float)(0.5 * (s_lo + s_hi));
+          // half width against the ROUNDED middle, rounded up
+          half = std::nextafter((float)(std::max(s_hi - (double)mid, (double)mid - s_lo) + pad), INFINITY);
+          if (!std::isfinite(mid) || std::fabs(mid) >= kNever) { mid = 0.0f; half = INFINITY; }
+        }
       }
-      if (!std::isfinite(s_lo) || !std::isfinite(s_hi)) { mid = 0.0f; half = INFINITY; }
-      else {
-        const double pad = 0x1p-19 * (std::fabs(s_lo) + std::fabs(s_hi) + 2.0);
-        mid = (float)(0.5 * (s_lo + s_hi));
-        // half width against the ROUNDED middle, rounded up
-        half = std::nextafter((float)(std::max(s_hi - (double)mid, (double)mid - s_lo) + pad), INFINITY);
-        if (!std::isfinite(mid) || std::fabs(mid) >= kNever) { mid = 0.0f; half = INFINITY; }
-      }
+      mids[(size_t)j] = mid;
+      if (half > halves[(size_t)(j / 4)]) halves[(size_t)(j / 4)] = half;
     }
-    c->host_span_mid[(size_t)j] = mid;
-    float& hg = c->host_span_half[(size_t)(j / 4)];
-    if (half > hg) hg = half;
   }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));   // a render may still be reading the old tables
@@ -527,8 +534,8 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
-  HIP_TRY(c->span_mid.reserve(sizeof(float) * (size_t)n_alloc));        // filled by refresh_spans once a camera is known
-  HIP_TRY(c->span_half.reserve(sizeof(float) * (size_t)n_groups_alloc));
+  HIP_TRY(c->span_mid.reserve(sizeof(float) * (size_t)n_alloc * 2));        // filled by refresh_spans once a camera is known
+  HIP_TRY(c->span_half.reserve(sizeof(float) * (size_t)n_groups_alloc * 2));
   HIP_TRY(c->geom_slab.reserve(sizeof(float) * slab.size()));
   HIP_TRY(hipMemcpyAsync(c->geom_slab.p, slab.data(), sizeof(float) * slab.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));

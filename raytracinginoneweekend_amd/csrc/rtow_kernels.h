@@ -24,8 +24,9 @@ struct TraceParams {
   const double4* geom64;     // (cx, cy, cz, r) per list entry in binary64: the exact test of primary rays
   const float* geom_slab;    // the slab test's radius per group of four (negative: never passes) for tables beyond kMaxSpheresKInLds entries
   const float* span_mid;     // interval test of the camera rays: per list entry the middle of the range of the image coordinate s
-                             // in which a camera ray can meet the sphere (n_geom_pad + 8 values) ...
-  const float* span_half;    // ... and per group of four the largest half width of its four ranges (negative: never passes)
+                             // in which a camera ray can meet the sphere (n_geom_pad + 8 values), then the same for t ...
+  const float* span_half;    // ... and per group of four the largest half width of its four ranges (negative: never passes;
+                             // n_geom_pad / 4 + 2 values for s, then as many for t)
   int n_geom_pad;
   int n_list;                // spheres in the list (= entries of geom64 and shade)
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin

@@ -730,36 +730,56 @@ static __device__ __forceinline__ void scan_bundle(geom_ptr geom, ExactPtr exact
 // (camera.nim:34), which runs across the image - outside which no camera ray can meet it, whatever its t and its point
 // on the lens (rtow_capi.hip, refresh_spans).  Every ray compares its own s with that range for every sphere of the
 // list, in list order: one packed subtraction per two spheres, |s - middle| of a group's four against the largest half
-// width among them (one scalar per group), five instructions per group where the filter takes seventeen.  Only the
-// groups in which some lane's ray passes fetch their centres and go through the filter and the exact tests, as in a
-// scan without any such test.  The test needs one number per ray and five per group; what it drops are spheres the
-// ray cannot meet, so hits, images and segment counts are those of the plain scan.
+// width among them (one scalar per group), five instructions per group where the filter takes seventeen.  The groups
+// in which some lane's ray passes see the same test for t, the coordinate up the image, and only those that pass
+// both go through the filter and the exact tests, as in a scan without any such test.  What the tests drop are
+// spheres the ray cannot meet, so hits, images and segment counts are those of the plain scan.
 typedef const f4v __attribute__((address_space(4)))* span_mid_ptr;
 typedef const float __attribute__((address_space(4)))* span_half_ptr;
 
+// middle - coordinate for a group's four spheres (one half of cv - HI selects which - for both lanes of a packed
+// subtraction), and the smallest of the four distances
+template <bool HI>
+static __device__ __forceinline__ float interval_distance(const f4v mid, const f2v cv) {
+  f2v d0, d1;
+  if (HI) {
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d0) : "s"(mid.xy), "v"(cv));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d1) : "s"(mid.zw), "v"(cv));
+  } else {
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d0) : "s"(mid.xy), "v"(cv));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d1) : "s"(mid.zw), "v"(cv));
+  }
+  return min_abs4(d0, d1);
+}
+
+// st = (s, t) of the lane's ray
 template <bool K_LDS, bool SHORT, typename ExactPtr>
-static __device__ __forceinline__ void interval_group(const f4v mid, const float half, const f2v sv, int g, geom_ptr geom,
+static __device__ __forceinline__ void interval_group(const f4v mid, const float half, const f2v st, int g, int n_groups, geom_ptr geom,
                                                       nk_lds_ptr nk, ExactPtr exact, CandList<SHORT>& cand, const ScanRay& r,
                                                       f3 o, f3 u, const PrimaryCtx& pc RTOW_PROF_PARAM) {
-  f2v d0, d1;   // middle - s for two spheres at a time (the low half of sv for both)
-  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d0) : "s"(mid.xy), "v"(sv));
-  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d1) : "s"(mid.zw), "v"(sv));
-  if (__ballot(min_abs4(d0, d1) <= half) == 0) return;   // wave-uniform: no ray of the wave can meet any of the four
-  RTOW_COUNT(24, 1);
+  if (__ballot(interval_distance<false>(mid, st) <= half) == 0) return;   // wave-uniform: no ray of the wave can meet any of the four
+  // One group in eleven gets here.  Its ranges of t and its centres are requested together and waited for once; the
+  // same test along the image's other axis then lets about one in five of these go on to the filter.
+  const span_mid_ptr mids_t = (span_mid_ptr)(uintptr_t)KARG(span_mid) + (n_groups + 2);
+  const span_half_ptr halves_t = (span_half_ptr)(uintptr_t)KARG(span_half) + (n_groups + 2);
+  const f4v mid_t = mids_t[g];
+  const float half_t = halves_t[g];
   f4v ka = {0, 0, 0, 0};
   const GroupRec grp = load_group<K_LDS, false>(geom, g, ka, nullptr);
   if (K_LDS) ka = nk[g];
+  if (__ballot(interval_distance<true>(mid_t, st) <= half_t) == 0) return;
+  RTOW_COUNT(24, 1);
   group_test<true, -1, false, !K_LDS>(grp, ka, nk, 4 * g, exact, cand, r, SlabRay{f2v{0.0f, 0.0f}, f2v{0.0f, 0.0f}}, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
 }
 
 template <bool K_LDS, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void scan_interval(geom_ptr geom, ExactPtr exact, const f4v* nk_lds, CandList<SHORT>& cand,
-                                                     int n_groups, float cmax, bool live, f3 o, f3 u, float s,
+                                                     int n_groups, float cmax, bool live, f3 o, f3 u, float s, float t,
                                                      const PrimaryCtx& pc RTOW_PROF_PARAM) {
   if (n_groups <= 0) return;
   ScanRay r = scan_ray(o, u, cmax);
-  if (!live) { r.ozt.y = INFINITY; s = INFINITY; }   // an infinite distance passes no finite half width, an infinite filter threshold nothing
-  const f2v sv = {s, s};
+  if (!live) { r.ozt.y = INFINITY; s = INFINITY; t = INFINITY; }   // an infinite distance passes no finite half width, an infinite filter threshold nothing
+  const f2v st = {s, t};
   const nk_lds_ptr nk = (nk_lds_ptr)nk_lds;
   const span_mid_ptr mids = (span_mid_ptr)(uintptr_t)KARG(span_mid);
   const span_half_ptr halves = (span_half_ptr)(uintptr_t)KARG(span_half);
@@ -773,13 +793,13 @@ static __device__ __forceinline__ void scan_interval(geom_ptr geom, ExactPtr exa
     const f4v mb = mids[g + 1];
     const float hb = halves[g + 1];
     __builtin_amdgcn_sched_barrier(0);
-    interval_group<K_LDS>(ma, ha, sv, g, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+    interval_group<K_LDS>(ma, ha, st, g, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
     asm volatile("" : : "s"(mb.x));
     __builtin_amdgcn_sched_barrier(0);
     ma = mids[g + 2];
     ha = halves[g + 2];
     __builtin_amdgcn_sched_barrier(0);
-    interval_group<K_LDS>(mb, hb, sv, g + 1, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+    interval_group<K_LDS>(mb, hb, st, g + 1, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
   }
   cand_drain<true>(cand, exact, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
 }
@@ -1195,8 +1215,8 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
         typedef const float __attribute__((address_space(4)))* karg_f32_ptr;
         static_assert(offsetof(TraceParams, slab_inv_rmin) == sizeof(CameraParams64), "slab_inv_rmin follows the camera");
         if constexpr (SLAB_AXIS == kIntervalTest) {
-          if (X_LDS) scan_interval<K_LDS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, (float)cs, pc RTOW_PROF_ARG);
-          else scan_interval<K_LDS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, (float)cs, pc RTOW_PROF_ARG);
+          if (X_LDS) scan_interval<K_LDS>(geom, exact_lds, nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, (float)cs, (float)ct, pc RTOW_PROF_ARG);
+          else scan_interval<K_LDS>(geom, (const f4v*)KARG(geom_exact), nk_lds, cand, KARG(n_geom_pad) / 4, KARG(cmax), gen, so, su, (float)cs, (float)ct, pc RTOW_PROF_ARG);
         } else if constexpr (SLAB_AXIS == kBundleTest) {
           // axis of the bundle: from the middle of the lens to the point the wave's first ray aims at (any axis is
           // valid - the spread of the rays is measured about it - this one sits in the middle of the lens)

@@ -384,7 +384,8 @@ def test_interval_test_of_camera_rays_is_conservative():
     line that touch the circle are the two tangents, and over the lens the extremes sit at its ends.  Restated here in
     numpy and held against the exact geometry of camera.nim:34-39 rays in binary64: for random look-at cameras (near,
     far, inside the field, wide and closed lenses) and random spheres, every ray whose LINE passes within |r| of a
-    centre has its s inside that sphere's range (widened as the kernel's binary32 subtraction needs), spheres wholly
+    centre has its s inside that sphere's range (widened as the kernel's binary32 subtraction needs) and, by the same
+    construction along the image's other axis, its t inside the sphere's range of t; spheres wholly
     behind the lens are met by no forward ray, and a sphere that reaches across the lens plane gets the whole axis."""
     import numpy as np
     rng = np.random.default_rng(17)
@@ -408,24 +409,26 @@ def test_interval_test_of_camera_rays_is_conservative():
         v = np.cross(w, u)
         hor, ver = focus * aspect * 2 * h * u, focus * 2 * h * v
         llc = look_from - hor / 2 - ver / 2 - focus * w
-        # the host's table
-        hu = np.linalg.norm(hor)
-        X, Z = (c - look_from) @ u, -((c - look_from) @ w)
-        rho = np.abs(r) * (1 + 1e-9) + 4e-9 * (hu + np.linalg.norm(ver) + focus + R + np.abs(X) + np.abs(Z)) * (1 + np.abs(Z) / focus)
-        never = Z < -rho
-        always = ~never & ~(Z > rho * (1 + 1e-6))
-        k = Z * Z - rho * rho
-        with np.errstate(invalid="ignore", divide="ignore"):
-            lo, hi = np.full(n, np.inf), np.full(n, -np.inf)
-            for xl in (-R * (1 + 1e-9), R * (1 + 1e-9)):
-                A = X - xl
-                root = rho * np.sqrt(A * A + k)
-                lo = np.minimum(lo, (xl + focus * (A * Z - root) / k) / hu + 0.5)
-                hi = np.maximum(hi, (xl + focus * (A * Z + root) / k) / hu + 0.5)
-        pad = 2.0 ** -19 * (np.abs(lo) + np.abs(hi) + 2)
-        mid = (0.5 * (lo + hi)).astype(f32)
-        half = (np.maximum(hi - mid.astype(np.float64), mid.astype(np.float64) - lo) + pad).astype(f32)
-        half = np.nextafter(half, f32(np.inf))
+        # the host's table, for s (across the image: drop v) and for t (up the image: drop u)
+        hu, hv = np.linalg.norm(hor), np.linalg.norm(ver)
+        tables = []
+        for across, extent in ((u, hu), (v, hv)):
+            X, Z = (c - look_from) @ across, -((c - look_from) @ w)
+            rho = np.abs(r) * (1 + 1e-9) + 4e-9 * (hu + hv + focus + R + np.abs(X) + np.abs(Z)) * (1 + np.abs(Z) / focus)
+            never = Z < -rho
+            always = ~never & ~(Z > rho * (1 + 1e-6))
+            k = Z * Z - rho * rho
+            with np.errstate(invalid="ignore", divide="ignore"):
+                lo, hi = np.full(n, np.inf), np.full(n, -np.inf)
+                for xl in (-R * (1 + 1e-9), R * (1 + 1e-9)):
+                    A = X - xl
+                    root = rho * np.sqrt(A * A + k)
+                    lo = np.minimum(lo, (xl + focus * (A * Z - root) / k) / extent + 0.5)
+                    hi = np.maximum(hi, (xl + focus * (A * Z + root) / k) / extent + 0.5)
+            pad = 2.0 ** -19 * (np.abs(lo) + np.abs(hi) + 2)
+            mid = (0.5 * (lo + hi)).astype(f32)
+            half = (np.maximum(hi - mid.astype(np.float64), mid.astype(np.float64) - lo) + pad).astype(f32)
+            tables.append((never, always, mid, np.nextafter(half, f32(np.inf))))
         # rays of getRay (camera.nim:34-39): lens point, focus-plane point; s and t a little beyond [0, 1] as the jitter allows
         m = 4000
         s, t = rng.uniform(-0.01, 1.01, m), rng.uniform(-0.01, 1.01, m)
@@ -441,10 +444,12 @@ def test_interval_test_of_camera_rays_is_conservative():
         meets = dist <= np.abs(r)[None, :]                      # the ray's LINE meets the sphere
         with np.errstate(invalid="ignore"):                     # ... at a point in front of the ray's origin (the far root)
             forward = meets & (along + np.sqrt(np.maximum(np.abs(r)[None, :] ** 2 - dist ** 2, 0.0)) > 0)
-        # the kernel's test in binary32
-        passes = np.abs(mid[None, :] - s.astype(f32)[:, None]) <= half[None, :]
-        passes = np.where(always[None, :], True, np.where(never[None, :], False, passes))
-        assert passes[forward].all(), (trial, int((~passes[forward]).sum()))
-        assert not forward[:, never].any()
-        checked += int(forward.sum()); inside += int(always.sum())
-    assert checked > 20000 and inside > 50
+        # the kernel's tests in binary32: both must let every such pair through
+        for (never, always, mid, half), coord in zip(tables, (s, t)):
+            passes = np.abs(mid[None, :] - coord.astype(f32)[:, None]) <= half[None, :]
+            passes = np.where(always[None, :], True, np.where(never[None, :], False, passes))
+            assert passes[forward].all(), (trial, int((~passes[forward]).sum()))
+            assert not forward[:, never].any()
+            inside += int(always.sum())
+        checked += int(forward.sum())
+    assert checked > 20000 and inside > 100
