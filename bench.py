@@ -35,8 +35,10 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak: 256 CU x 2.4 GHz x 256
 FLOP_PER_TEST = 18             # hitrecord.nim:56-61: oc 3, half_b 5, |oc|^2 5, r*r 1, c 1, disc 3
 FLOP_PER_SEGMENT_EXTRA = 65    # a = |dir|^2 once, hit epilogue, scatter, sky (amortised)
 FLOP_PER_TEST_EXECUTED = 14    # what the kernel's screen really issues per sphere: 7 packed FMAs per pair
-FLOP_PER_SLAB_TEST = 6         # camera rays (one pixel's samples per wave) see a 3-FMA slab test first; the groups of four
-                               # spheres that pass it in some lane go on to the screen: slab_pass_fraction() below
+# camera rays (one pixel's samples per wave) see a cheaper necessary condition per (ray, sphere) pair first, and only the
+# groups of four spheres that pass it in some lane go on to the screen (screen_pass_fraction() below):
+FLOP_PER_CAMERA_TEST = {"interval": 1, "slab": 4, "none": 0}   # one subtraction; two FMAs; nothing
+SCREEN_NAMES = {0: "none", 1: "slab", 2: "interval", 3: "bundle"}   # rtow_stats.camera_screen
 
 WORKLOADS = {
     # name: (width, height, spp, depth, half_extent, lambert_below, metal_below)
@@ -46,15 +48,15 @@ WORKLOADS = {
 }
 
 
-def slab_pass_fraction(workload, spp):
-    """Share of a PRIMARY scan's groups that go on from the slab test to the screen, measured per workload with the
-    instrumented build (profiles/r*_slab_pass_fraction.json).  None for a configuration it was not measured on
-    (another sample count changes which rays share a wavefront)."""
+def screen_pass_fraction(workload, spp, screen):
+    """Share of a PRIMARY scan's groups that go on from the camera rays' first test to the 7-FMA screen, measured per
+    workload and per kind of test with the instrumented build (profiles/r*_screen_pass_fraction.json).  None for a
+    configuration it was not measured on (another sample count changes which rays share a wavefront)."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_slab_pass_fraction.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_screen_pass_fraction.json")))
     if not found or spp != WORKLOADS[workload][2]:
         return None
-    return json.load(open(found[-1])).get(workload)
+    return json.load(open(found[-1])).get(screen, {}).get(workload)
 
 
 def hbm_traffic(workload, spp, world):
@@ -289,9 +291,10 @@ def main():
     trace_ms = [sorted(st["trace_ms"] for st in serial)[mid]]  # transients between phases) does not decide
     total_ms = [sorted(st["total_ms"] for st in serial)[mid]]
     clock_mhz = sorted(st.get("shader_clock_mhz", 0.0) for st in serial)[mid]   # what the chip sustained under the kernel
-    # the same three steps with the slab test of the camera rays switched off (RTOW_NO_SLAB_TEST is read at every
-    # launch and selects the kernel instance without it): every ray-sphere pair then goes through the 7-FMA screen
-    slab_used = "RTOW_NO_SLAB_TEST" not in os.environ
+    # the same three steps with nothing in front of the camera rays' screen (RTOW_NO_SLAB_TEST is read at every launch
+    # and selects the kernel instance without a first test): every ray-sphere pair then goes through the 7-FMA screen
+    screen = SCREEN_NAMES.get(serial[-1].get("camera_screen", 0), "none")
+    slab_used = screen != "none"
     no_slab_ms = None
     if slab_used:
         os.environ["RTOW_NO_SLAB_TEST"] = "1"
@@ -299,24 +302,29 @@ def main():
         for i in range(n_serial):
             enqueue(i)
             plain.append(finish(i))
-            note(f"step {i + 1} of {n_serial} without the slab test")
+            note(f"step {i + 1} of {n_serial} without a first test of the camera rays")
         del os.environ["RTOW_NO_SLAB_TEST"]
         assert plain[-1]["ray_segments"] == serial[-1]["ray_segments"]
         no_slab_ms = sorted(st["trace_ms"] for st in plain)[mid]
-    # and with the optional bundle test (RTOW_CAMERA_SCREEN=bundle): a wave's 64 camera rays are tested against the
-    # table as one packet first.  That is culling per packet, not brute force per ray, so it is never part of `value`
-    # or `frac`; the figure is reported for what it is.
-    bundle_ms = None
-    if slab_used and "RTOW_SLAB_AXIS" not in os.environ and "RTOW_CAMERA_SCREEN" not in os.environ:
-        os.environ["RTOW_CAMERA_SCREEN"] = "bundle"
-        packet = []
+    # the older per-ray test (RTOW_CAMERA_SCREEN=slab), and the optional bundle test (RTOW_CAMERA_SCREEN=bundle): a wave's
+    # 64 camera rays tested against the table as one packet first.  That is culling per packet, not brute force per
+    # ray, so it is never part of `value` or `frac`; the figure is reported for what it is.
+    def variant(setting):
+        os.environ["RTOW_CAMERA_SCREEN"] = setting
+        steps = []
         for i in range(n_serial):
             enqueue(i)
-            packet.append(finish(i))
-            note(f"step {i + 1} of {n_serial} with the bundle test")
+            steps.append(finish(i))
+            note(f"step {i + 1} of {n_serial} with RTOW_CAMERA_SCREEN={setting}")
         del os.environ["RTOW_CAMERA_SCREEN"]
-        assert packet[-1]["ray_segments"] == serial[-1]["ray_segments"]
-        bundle_ms = sorted(st["trace_ms"] for st in packet)[mid]
+        assert steps[-1]["ray_segments"] == serial[-1]["ray_segments"]
+        return sorted(st["trace_ms"] for st in steps)[mid]
+
+    bundle_ms = slab_ms = None
+    if slab_used and "RTOW_SLAB_AXIS" not in os.environ and "RTOW_CAMERA_SCREEN" not in os.environ:
+        if screen == "interval":
+            slab_ms = variant("slab")
+        bundle_ms = variant("bundle")
 
     # the frame assembled from all ranks' tiles against the same frame rendered whole on rank 0
     image_verified = None
@@ -339,12 +347,12 @@ def main():
         avg_trace_s = sum(trace_ms) / len(trace_ms) * 1e-3
         achieved = serial[-1]["ray_segments"] * flop_per_segment / avg_trace_s / 1e12
         paths = width * height * spp
-        pass_fraction = slab_pass_fraction(args.workload, spp) if slab_used else 0.0
-        if pass_fraction is None:
+        pass_fraction = screen_pass_fraction(args.workload, spp, screen) if slab_used else 0.0
+        if pass_fraction is None or screen not in FLOP_PER_CAMERA_TEST:
             executed = None
         else:
             executed = ((serial[-1]["ray_segments"] - (serial[-1]["paths"] if slab_used else 0)) * FLOP_PER_TEST_EXECUTED
-                        + (serial[-1]["paths"] * (FLOP_PER_SLAB_TEST + pass_fraction * FLOP_PER_TEST_EXECUTED) if slab_used else 0)
+                        + (serial[-1]["paths"] * (FLOP_PER_CAMERA_TEST[screen] + pass_fraction * FLOP_PER_TEST_EXECUTED) if slab_used else 0)
                         ) * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS
         out = {
             "metric": "Mrays/sec (ray segments = world.hit queries) book-1 final scene 1200x800 spp500 depth50"
@@ -389,15 +397,22 @@ def main():
                 # `achieved` counts the reference's work (18 FLOP per ray-sphere test, hitrecord.nim:56-61); the
                 # kernel screens every sphere with 14 FLOP (7 packed FMAs per pair) and runs the full test on
                 # the ~1.2 survivors per ray, so the share of the VALU peak it really issues is lower:
-                # (camera-ray segments - one per path - see the 6-FLOP slab test and the screen for the groups that pass it)
+                # (camera-ray segments - one per path - see the first test, one subtraction per pair for the interval
+                # test, and the screen only for the groups that pass it)
                 "frac_executed_screen_only": executed,
-                "slab_pass_fraction": pass_fraction if slab_used else None,
+                "camera_ray_first_test": screen,
+                "first_test_pass_fraction": pass_fraction if slab_used else None,
                 "note": "achieved = ray segments x the reference's 18 FLOP per ray-sphere pair (+65 per segment); the kernel decides "
-                        "most pairs with fewer operations (3 FMAs for camera rays, 7 otherwise: frac_executed_screen_only), so frac "
-                        "measures work delivered against the VALU peak and can approach or exceed 1 on long sphere lists",
-                "slab_test_for_camera_rays": slab_used,
+                        "most pairs with fewer operations (one subtraction for a camera ray's pair, 7 FMAs otherwise: "
+                        "frac_executed_screen_only), so frac measures work delivered against the VALU peak and can approach or "
+                        "exceed 1; frac_without_first_test is the same frame with every pair going through the 7-FMA screen",
+                "kernel_ms_without_first_test": no_slab_ms,
+                "frac_without_first_test": (serial[-1]["ray_segments"] * flop_per_segment / (no_slab_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if no_slab_ms else None,
+                # (the names these two figures had before the interval test replaced the slab test as the default)
                 "kernel_ms_without_slab_test": no_slab_ms,
                 "frac_without_slab_test": (serial[-1]["ray_segments"] * flop_per_segment / (no_slab_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if no_slab_ms else None,
+                "kernel_ms_with_slab_test_instead": slab_ms,
+                "frac_with_slab_test_instead": None if slab_ms is None else serial[-1]["ray_segments"] * flop_per_segment / (slab_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                 # NOT the headline and not brute force: the same frame with RTOW_CAMERA_SCREEN=bundle, where each wave
                 # tests the table against its 64 camera rays as one packet before any per-ray test (same image)
                 "optional_bundle_test": None if bundle_ms is None else {

@@ -13,6 +13,8 @@ type
     nSpheres*, nBig*: int32
     shaderClockMhz*: cfloat
     gatherPath*: int32                    ## RTOW_GATHER_*: how rtow_render_multi brought the rows home
+    cameraScreen*: int32                  ## RTOW_SCREEN_*: what the camera rays saw in front of the sphere screen
+    reserved: int32
 
 proc rtow_last_error*(): cstring {.importc, dynlib: rtowLib.}
 proc rtow_create*(device: cint, ctx: ptr RtowCtx): cint {.importc, dynlib: rtowLib.}

@@ -69,6 +69,18 @@ enum {
   RTOW_GATHER_HOST_AFTER_RCCL = 3  /* RCCL was asked for but could not be used or failed: rows copied to the host in turn */
 };
 
+/* What the camera rays of a context's last render saw in front of the sphere screen (rtow_stats.camera_screen).
+ * None of them changes a hit, an image or a segment count; they differ in cost only. */
+enum {
+  RTOW_SCREEN_NONE = 0,      /* nothing: every camera ray puts every sphere through the screen (RTOW_NO_SLAB_TEST) */
+  RTOW_SCREEN_SLAB = 1,      /* per (ray, sphere): distance between centre and the ray's line seen along one world axis */
+  RTOW_SCREEN_INTERVAL = 2,  /* per (ray, sphere): the ray's image coordinates against the ranges in which the sphere can
+                                be met at all (tables made by the library from scene and camera); the default for the
+                                camera initCamera builds (camera.nim:12-31), other cameras get the slab test */
+  RTOW_SCREEN_BUNDLE = 3     /* per (wave, sphere): the list against a wave's 64 camera rays as one packet; only with
+                                RTOW_CAMERA_SCREEN=bundle - packet culling, not brute force per ray */
+};
+
 /* The eight private fields of Camera (camera.nim:4-10), rounded to binary32 by the host after
  * initCamera (camera.nim:12-31) has computed them in binary64. */
 typedef struct {
@@ -103,6 +115,8 @@ typedef struct {
   float shader_clock_mhz; /* clock the GPU ran at during that kernel: shader-clock ticks per tick of the
                              constant 100 MHz counter, read by the kernel's first wave as it starts and retires */
   int32_t gather_path;    /* RTOW_GATHER_*: set on every context of the last rtow_render_multi call */
+  int32_t camera_screen;  /* RTOW_SCREEN_*: what the camera rays of that render saw in front of the sphere screen */
+  int32_t reserved_;
 } rtow_stats;
 
 /* Message of the last failing call on this thread ("" if none). */

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("RTOW_LIB_PATH") or os.path.join(_HERE, "lib", "librto
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 HT_SPHERE = 0                                   # HittableKind (hittables.nim:4-5)
 GATHER_NONE, GATHER_HOST, GATHER_RCCL, GATHER_HOST_AFTER_RCCL = 0, 1, 2, 3   # rtow_stats.gather_path
+SCREEN_NONE, SCREEN_SLAB, SCREEN_INTERVAL, SCREEN_BUNDLE = 0, 1, 2, 3          # rtow_stats.camera_screen
 
 
 class RtowError(RuntimeError):
@@ -41,7 +42,8 @@ class CameraStruct64(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ray_segments", C.c_uint64), ("paths", C.c_uint64), ("trace_ms", C.c_float),
                 ("total_ms", C.c_float), ("n_spheres", C.c_int32), ("n_big", C.c_int32),
-                ("shader_clock_mhz", C.c_float), ("gather_path", C.c_int32)]
+                ("shader_clock_mhz", C.c_float), ("gather_path", C.c_int32), ("camera_screen", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 # every symbol include/rtow.h declares

@@ -163,6 +163,7 @@ struct rtow_ctx {
   std::vector<uint8_t> host_regular;          // per list entry: 1 = in the binary32 table (|radius| < kBigRadius)
   std::vector<float> host_span_mid, host_span_half;   // staging of the uploads (must outlive the copies); s ranges, then t ranges
   bool spans_valid = false;                   // the tables match the current scene and camera, and the camera is a regular one
+  int screen_launched = 0;                    // RTOW_SCREEN_* of the frame in flight
   rtow::CameraParams64 cam;
 
   // per-render workspace
@@ -231,7 +232,7 @@ extern "C" {
 
 const char* rtow_last_error(void) { return g_err.c_str(); }
 
-int rtow_version(void) { return 101; }
+int rtow_version(void) { return 10100; }   // 1.1.0: rtow_stats grew by camera_screen
 
 int rtow_device_count(int* count) {
   if (!count) return fail(RTOW_ERR_INVALID, "rtow_device_count: count is NULL");
@@ -677,6 +678,8 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
     if (!strcmp(s, "bundle")) slab_axis = rtow::kBundleTest;
     else if (!strcmp(s, "slab")) slab_axis = c->slab_axis;
   }
+  c->screen_launched = slab_axis < 0 ? RTOW_SCREEN_NONE : slab_axis == rtow::kIntervalTest ? RTOW_SCREEN_INTERVAL
+                     : slab_axis == rtow::kBundleTest ? RTOW_SCREEN_BUNDLE : RTOW_SCREEN_SLAB;
   if (n_pixels) rtow::launch_trace(p, slab_axis, grid, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
@@ -773,6 +776,8 @@ int rtow_sync(rtow_ctx* c) {
     c->stats.n_spheres = c->n_spheres;
     c->stats.n_big = c->n_big;
     c->stats.gather_path = RTOW_GATHER_NONE;   // rtow_render_multi sets it once its rows are home
+    c->stats.camera_screen = c->screen_launched;
+    c->stats.reserved_ = 0;
     {
       const uint64_t ticks = c->host_counters[4] - c->host_counters[2], ref = c->host_counters[5] - c->host_counters[3];
       c->stats.shader_clock_mhz = ref > 0 && c->host_counters[5] > c->host_counters[3] ? (float)((double)ticks / (double)ref * 100.0) : 0.0f;

@@ -32,7 +32,8 @@ namespace rtow {
 // [5] hand-out, [1] [2] [13] set-up, scan, shading of PRIMARY iterations, [6] [7] [8] of BOUNCE iterations, [15] all;
 // lanes: [16] BOUNCE segments ending on the sky, [17] [18] [19] hitting a Lambertian / metal / dielectric sphere,
 // [20] lanes still looking for a unit-ball point, summed over those passes, [21] [22] PRIMARY rays missing / hitting, [23] lanes taking a pooled path,
-// [24] groups of a PRIMARY scan that pass the slab test
+// [24] groups of a PRIMARY scan that go on to the filter (past the slab, bundle or interval tests), [25] groups that pass the
+// interval test's first axis
 __device__ unsigned long long g_prof[32];
 
 // wave-local accumulation (values are wave-uniform), flushed once when the wave retires
@@ -758,6 +759,7 @@ static __device__ __forceinline__ void interval_group(const f4v mid, const float
                                                       nk_lds_ptr nk, ExactPtr exact, CandList<SHORT>& cand, const ScanRay& r,
                                                       f3 o, f3 u, const PrimaryCtx& pc RTOW_PROF_PARAM) {
   if (__ballot(interval_distance<false>(mid, st) <= half) == 0) return;   // wave-uniform: no ray of the wave can meet any of the four
+  RTOW_COUNT(25, 1);
   // One group in eleven gets here.  Its ranges of t and its centres are requested together and waited for once; the
   // same test along the image's other axis then lets about one in five of these go on to the filter.
   const span_mid_ptr mids_t = (span_mid_ptr)(uintptr_t)KARG(span_mid) + (n_groups + 2);

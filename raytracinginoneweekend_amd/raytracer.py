@@ -217,7 +217,8 @@ class Renderer:
         self._check(self._lib.rtow_get_stats(self._h, C.byref(s)))
         return {"ray_segments": s.ray_segments, "paths": s.paths, "trace_ms": s.trace_ms,
                 "total_ms": s.total_ms, "n_spheres": s.n_spheres, "n_big": s.n_big,
-                "shader_clock_mhz": s.shader_clock_mhz, "gather_path": s.gather_path}
+                "shader_clock_mhz": s.shader_clock_mhz, "gather_path": s.gather_path,
+                "camera_screen": s.camera_screen}
 
     def stream(self):
         p = C.c_void_p()

@@ -1,9 +1,11 @@
-"""What the slab test of the camera rays is worth, and what that depends on.
+"""What the cheap per-ray tests in front of the camera rays' screen are worth, and what that depends on.
 
-The test lets a wave skip the 7-FMA screen for a group of four spheres when none of its 64 camera rays comes near
+The default is the interval test (the ray's image coordinates against the ranges in which a sphere can be met at
+all); RTOW_CAMERA_SCREEN=slab selects the older slab test (distance to the ray's line seen along a world axis).
+Either lets a wave skip the 7-FMA screen for a group of four spheres when none of its 64 camera rays passes for
 any of them.  Those 64 rays are consecutive (pixel, sample) pairs of a chunk: 64 samples of ONE pixel when
 spp >= 64, several neighbouring pixels of a row when spp is smaller, and the lens spreads their origins over the
-aperture.  This script renders the same frame with the test and with RTOW_NO_SLAB_TEST=1 (read at every launch)
+aperture.  This script renders the same frame with the default test, with the slab test and with RTOW_NO_SLAB_TEST=1 (read at every launch)
 over sample counts, apertures, a camera inside the sphere field, the all metal / glass scene and the
 10 001-sphere scene, and reports trace-kernel times (HIP events, median of 3) and - from the instrumented
 build, when it is present - how many groups of a PRIMARY scan go on to the screen.
@@ -45,9 +47,11 @@ for spp in ((1, 8, 64) if not quick else (8,)):
     cases.append(("10 001 spheres", "camera inside the field at (1, 0.5, 1)", inside, spp))
 
 
-def timed(r, spp, no_slab):
-    if no_slab:
+def timed(r, spp, mode):
+    if mode == "none":
         os.environ["RTOW_NO_SLAB_TEST"] = "1"
+    elif mode == "slab":
+        os.environ["RTOW_CAMERA_SCREEN"] = "slab"
     try:
         ms = []
         r.renderAsync(W, H, spp, DEPTH); r.sync()     # one untimed launch of this kernel instance first
@@ -57,6 +61,7 @@ def timed(r, spp, no_slab):
         return statistics.median(ms), r.stats()["ray_segments"]
     finally:
         os.environ.pop("RTOW_NO_SLAB_TEST", None)
+        os.environ.pop("RTOW_CAMERA_SCREEN", None)
 
 
 # timing first, all of it with the product build; the instrumented build runs afterwards, so that its slow launches
@@ -71,10 +76,11 @@ for scene_name, cam_name, cam, spp in cases:
         r = R.Renderer(0); r.setWorld(scenes[scene_name])
         current = scene_name
     r.setCamera(cam)
-    t_with, seg = timed(r, spp, False)
-    t_without, seg2 = timed(r, spp, True)
-    assert seg == seg2
-    rows.append([scene_name, cam_name, cam, spp, t_with, t_without, seg, ""])
+    t_with, seg = timed(r, spp, "default")
+    t_slab, seg3 = timed(r, spp, "slab")
+    t_without, seg2 = timed(r, spp, "none")
+    assert seg == seg2 == seg3
+    rows.append([scene_name, cam_name, cam, spp, t_with, t_without, seg, "", t_slab])
     print(f"timed {scene_name} / {cam_name} / spp {spp}", file=sys.stderr, flush=True)
 r.close()
 if prof is not None:
@@ -96,10 +102,10 @@ if prof is not None:
         prof.rtow_debug_counters(b, 0)
         groups = (n + 7) // 8 * 2
         row[7] = f"{b[24] / max(1, b[14]):7.1f} of {groups} = {b[24] / max(1, b[14]) / groups:.3f}"
-print(f"{'scene':22s} {'camera':40s} {'spp':>4s} {'with ms':>9s} {'without ms':>10s} {'gain':>7s} {'Mrays/s':>9s} {'frac':>6s} {'no-slab frac':>12s} "
+print(f"{'scene':22s} {'camera':40s} {'spp':>4s} {'interval ms':>11s} {'slab ms':>9s} {'without ms':>10s} {'gain':>7s} {'slab gain':>9s} {'Mrays/s':>9s} {'frac':>6s} {'no-test frac':>12s} "
       f"{'groups on to the screen':>24s}")
-for scene_name, cam_name, cam, spp, t_with, t_without, seg, passing in rows:
+for scene_name, cam_name, cam, spp, t_with, t_without, seg, passing, t_slab in rows:
     n = len(scenes[scene_name])
     flop = seg * (18 * n + 65)
-    print(f"{scene_name:22s} {cam_name:40s} {spp:4d} {t_with:9.3f} {t_without:10.3f} {100 * (t_without / t_with - 1):6.1f}% "
+    print(f"{scene_name:22s} {cam_name:40s} {spp:4d} {t_with:11.3f} {t_slab:9.3f} {t_without:10.3f} {100 * (t_without / t_with - 1):6.1f}% {100 * (t_without / t_slab - 1):8.1f}% "
           f"{seg / t_with / 1e3:9.1f} {flop / t_with / 1e9 / 157.3:6.3f} {flop / t_without / 1e9 / 157.3:12.3f} {passing:>24s}", flush=True)
