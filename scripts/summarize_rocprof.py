@@ -24,7 +24,7 @@ if os.path.exists(trace):
     rows = list(c.execute("select name,start,end,duration,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size "
                           "from kernels where name like '%trace%' order by start"))
     t0 = rows[0][1] if rows else 0
-    main = rows[0][0] if rows else ""   # the instance the timed region runs; bench.py ends with a few launches of the instance without the slab test
+    main = rows[0][0] if rows else ""   # the instance the timed region runs; bench.py ends with a few launches of the other instances
     prev_end = None
     others = {}
     for k, r in enumerate(rows):
@@ -52,19 +52,29 @@ for db in sorted(glob.glob(os.path.join(prof, "pmc_*", "pmc_results.db"))):
             continue
         if main_pmc is None:
             main_pmc = name           # the first trace dispatch of a pass: the instance the timed region runs
-        if name != main_pmc:          # the instance without the slab test, launched at the end of bench.py
-            pmc_other.setdefault(counter, []).append(value)
+        if name != main_pmc:          # the other instances bench.py launches at the end: no first test, slab test, bundle test
+            pmc_other.setdefault(name, {}).setdefault(counter, []).append(value)
             continue
         pmc.setdefault(counter, []).append(value)
 rows = [f"# rocprofv3 --pmc passes, {main_pmc}, one value per dispatch (sum over XCDs/SEs)",
         "counter,per_dispatch_values"]
 for k in sorted(pmc):
     rows.append(k + "," + " ".join(f"{v:.6g}" for v in pmc[k]))
-if pmc_other:
+# the last template argument of rtow_trace_kernel says what the camera rays see before the sphere screen
+labels = {"-1": "nothing in front of the screen (RTOW_NO_SLAB_TEST)", "0": "slab test along x", "1": "slab test along y",
+          "2": "slab test along z", "3": "bundle test (RTOW_CAMERA_SCREEN=bundle: packet culling, not part of any quoted figure)",
+          "4": "interval test (the default)"}
+def label(name):
+    import re
+    m = re.search(r"rtow_trace_kernel<[^>]*,\s*(-?\d+)>", name)
+    return labels.get(m.group(1), name) if m else name
+rows[0] += f"  [{label(main_pmc or '')}]"
+for other in pmc_other:
     rows.append("")
-    rows.append("# the same counters for the launches of the instance without the slab test (end of bench.py)")
-    for k in sorted(pmc_other):
-        rows.append(k + "," + " ".join(f"{v:.6g}" for v in pmc_other[k]))
+    rows.append(f"# the same counters for the launches of {other}  [{label(other)}] at the end of bench.py")
+    for k in sorted(pmc_other[other]):
+        rows.append(k + "," + " ".join(f"{v:.6g}" for v in pmc_other[other][k]))
+if pmc_other:
     rows.append("")
 # figures derived from the LAST dispatch of each pass (a launch that ran alone).  SQ counters count quad-cycles
 # summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs.
