@@ -333,7 +333,7 @@ static int refresh_spans(rtow_ctx* c) {
               std::fabs(F[k] - f * w[k]) <= 1e-9 * (f + hu + hv) && std::isfinite(cam.origin[k]);
   if (!regular) return RTOW_OK;
 
-  const int n = c->n_spheres, n_alloc = c->n_geom_pad + 8;
+  const int n = c->n_spheres, n_alloc = c->n_geom_pad + 4 * rtow::kSpanPadGroups;   // padding: see scan_interval
   const float kNever = 1e30f;
   // the same construction along the image's other axis (drop u instead of v) bounds the second argument of getRay, t
   c->host_span_mid.assign((size_t)n_alloc * 2, kNever);
@@ -535,8 +535,8 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   HIP_TRY(c->geom.reserve(sizeof(float) * geom.size()));
   HIP_TRY(c->geom_rr.reserve(sizeof(float4) * exact.size()));
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
-  HIP_TRY(c->span_mid.reserve(sizeof(float) * (size_t)n_alloc * 2));        // filled by refresh_spans once a camera is known
-  HIP_TRY(c->span_half.reserve(sizeof(float) * (size_t)n_groups_alloc * 2));
+  HIP_TRY(c->span_mid.reserve(sizeof(float) * (size_t)(n_pad + 4 * rtow::kSpanPadGroups) * 2));        // filled by refresh_spans once a camera is known
+  HIP_TRY(c->span_half.reserve(sizeof(float) * (size_t)(n_pad / 4 + rtow::kSpanPadGroups) * 2));
   HIP_TRY(c->geom_slab.reserve(sizeof(float) * slab.size()));
   HIP_TRY(hipMemcpyAsync(c->geom_slab.p, slab.data(), sizeof(float) * slab.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));

@@ -24,9 +24,9 @@ struct TraceParams {
   const double4* geom64;     // (cx, cy, cz, r) per list entry in binary64: the exact test of primary rays
   const float* geom_slab;    // the slab test's radius per group of four (negative: never passes) for tables beyond kMaxSpheresKInLds entries
   const float* span_mid;     // interval test of the camera rays: per list entry the middle of the range of the image coordinate s
-                             // in which a camera ray can meet the sphere (n_geom_pad + 8 values), then the same for t ...
+                             // in which a camera ray can meet the sphere (n_geom_pad + 4 kSpanPadGroups values), then the same for t ...
   const float* span_half;    // ... and per group of four the largest half width of its four ranges (negative: never passes;
-                             // n_geom_pad / 4 + 2 values for s, then as many for t)
+                             // n_geom_pad / 4 + kSpanPadGroups values for s, then as many for t)
   int n_geom_pad;
   int n_list;                // spheres in the list (= entries of geom64 and shade)
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin
@@ -93,6 +93,7 @@ void launch_scatter(const ScatterParams& p, hipStream_t stream);
 // bundle test (kBundleTest; see scan_bundle), the interval test (kIntervalTest; see scan_interval), or -1 for nothing
 constexpr int kBundleTest = 3;
 constexpr int kIntervalTest = 4;
+constexpr int kSpanPadGroups = 4;   // all-padding groups behind the last one in the interval test's tables (its loop requests two pairs ahead)
 void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,
                     hipStream_t stream);

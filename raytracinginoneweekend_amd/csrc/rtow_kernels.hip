@@ -762,8 +762,8 @@ static __device__ __forceinline__ void interval_group(const f4v mid, const float
   RTOW_COUNT(25, 1);
   // One group in eleven gets here.  Its ranges of t and its centres are requested together and waited for once; the
   // same test along the image's other axis then lets about one in five of these go on to the filter.
-  const span_mid_ptr mids_t = (span_mid_ptr)(uintptr_t)KARG(span_mid) + (n_groups + 2);
-  const span_half_ptr halves_t = (span_half_ptr)(uintptr_t)KARG(span_half) + (n_groups + 2);
+  const span_mid_ptr mids_t = (span_mid_ptr)(uintptr_t)KARG(span_mid) + (n_groups + kSpanPadGroups);
+  const span_half_ptr halves_t = (span_half_ptr)(uintptr_t)KARG(span_half) + (n_groups + kSpanPadGroups);
   const f4v mid_t = mids_t[g];
   const float half_t = halves_t[g];
   f4v ka = {0, 0, 0, 0};
@@ -783,25 +783,33 @@ static __device__ __forceinline__ void scan_interval(geom_ptr geom, ExactPtr exa
   if (!live) { r.ozt.y = INFINITY; s = INFINITY; t = INFINITY; }   // an infinite distance passes no finite half width, an infinite filter threshold nothing
   const f2v st = {s, t};
   const nk_lds_ptr nk = (nk_lds_ptr)nk_lds;
-  const span_mid_ptr mids = (span_mid_ptr)(uintptr_t)KARG(span_mid);
-  const span_half_ptr halves = (span_half_ptr)(uintptr_t)KARG(span_half);
-  f4v ma = mids[0];
-  float ha = halves[0];
-  // (the empty asm statements make the wait for a group's scalar loads land before the next group is requested: see
-  // the slab loop of scan_regular; the tables hold two all-padding groups behind the last one)
-  for (int g = 0; g < n_groups; g += 2) {
-    asm volatile("" : : "s"(ma.x));
+  // Two groups per scalar load: the middles of eight spheres and two half widths.  A wait for scalar loads is a wait
+  // for all of them (they return out of order), so the request for the next pair is issued right AFTER the wait for
+  // the current one - the empty asm statements read a register of the pair about to be used, which is where the wait
+  // lands - and then has two groups' worth of work (of this wave and of the four others of the SIMD) to arrive in.
+  // The tables hold four all-padding groups behind the last one.
+  typedef const f8v __attribute__((address_space(4)))* mid_pair_ptr;
+  typedef const f2v __attribute__((address_space(4)))* half_pair_ptr;
+  const mid_pair_ptr mids = (mid_pair_ptr)(uintptr_t)KARG(span_mid);
+  const half_pair_ptr halves = (half_pair_ptr)(uintptr_t)KARG(span_half);
+  f8v ma = mids[0];
+  f2v ha = halves[0];
+  for (int g = 0; g < n_groups; g += 4) {
+    asm volatile("" : : "s"(ma.s0));
     __builtin_amdgcn_sched_barrier(0);
-    const f4v mb = mids[g + 1];
-    const float hb = halves[g + 1];
+    const f8v mb = mids[g / 2 + 1];
+    const f2v hb = halves[g / 2 + 1];
     __builtin_amdgcn_sched_barrier(0);
-    interval_group<K_LDS>(ma, ha, st, g, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
-    asm volatile("" : : "s"(mb.x));
+    interval_group<K_LDS>(ma.lo, ha.x, st, g, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+    interval_group<K_LDS>(ma.hi, ha.y, st, g + 1, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+    asm volatile("" : : "s"(mb.s0));
     __builtin_amdgcn_sched_barrier(0);
-    ma = mids[g + 2];
-    ha = halves[g + 2];
+    ma = mids[g / 2 + 2];
+    ha = halves[g / 2 + 2];
     __builtin_amdgcn_sched_barrier(0);
-    interval_group<K_LDS>(mb, hb, st, g + 1, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+    // (when the number of groups is no multiple of four these two are padding: they pass nothing)
+    interval_group<K_LDS>(mb.lo, hb.x, st, g + 2, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
+    interval_group<K_LDS>(mb.hi, hb.y, st, g + 3, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
   }
   cand_drain<true>(cand, exact, o, u, 0.0f, -1, pc RTOW_PROF_ARG);
 }
