@@ -15,7 +15,8 @@
 // The sphere scan (hittables.nim:79-88 over hitrecord.nim:55-63) keeps the ray in VGPRs and
 // streams the sphere table through SGPRs with wave-uniform scalar loads, four spheres per load,
 // two spheres per packed FP32 instruction, and a rarely taken branch for discriminant >= 0; camera
-// rays - 64 samples of one pixel per wave - see a cheaper slab test first.
+// rays - 64 samples of one pixel per wave - see a cheaper per-ray test first (scan_interval; pair_slab for cameras
+// the interval test does not cover).
 //  rtow_rays_kernel, rtow_get_rays_kernel, rtow_scatter_kernel   the reference's per-ray procs (rayColor / hit,
 //                      getRay, scatter) for batches of caller-given rays, one lane per ray.
 //  ppm_*_kernel        the P3 text of the image, composed on the device.

@@ -778,6 +778,49 @@ def test_camera_the_interval_test_does_not_cover_falls_back_to_the_slab_test(ora
         assert (got32[0] == plain32[0]).all() and (got32[2] == plain32[2]).all()
 
 
+def test_interval_test_on_random_cameras_and_worlds(monkeypatch):
+    """The interval test's tables come from host code that sees scene and camera (ranges of the image coordinates per
+    sphere).  Forty seeded random look-at cameras - near, far and inside the field, looking up, down and along the
+    ground, closed to very wide lenses, focus in front of and behind the spheres, rolled - on the book scene and on
+    random worlds with overlapping spheres of either sign of radius: the image with the test must be the image
+    without it (hit ids, 64-bit sums, pixels, segment count), and the stats must say which test ran."""
+    from raytracinginoneweekend_amd import _lib
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    R = _R()
+    rng = np.random.default_rng(20261112)
+    W, H, depth = 72, 48, 50
+    with R.Renderer(0) as r:
+        for case in range(40):
+            if case % 4 == 0:
+                r.setWorld(R.randomScene() if case % 8 == 0 else R.randomScene(halfExtent=int(rng.integers(3, 30))))
+            elif case % 4 == 2:
+                n = int(rng.integers(1, 60))
+                r.setWorld({"center_x": rng.uniform(-4, 4, n), "center_y": rng.uniform(-1, 3, n), "center_z": rng.uniform(-4, 4, n),
+                            "radius": rng.uniform(0.05, 2.0, n) * rng.choice([1.0, -1.0], n), "kind": rng.integers(0, 3, n),
+                            "albedo": rng.uniform(0, 1, (n, 3)), "fuzz": rng.uniform(0, 0.5, n), "ir": np.full(n, 1.5)})
+            scale = float(rng.choice([0.5, 4.0, 14.0, 60.0]))
+            look_from = rng.normal(0, 1, 3) * scale
+            look_from[1] = abs(look_from[1]) * float(rng.choice([0.05, 1.0]))
+            look_at = rng.normal(0, 1, 3) * float(rng.choice([0.5, 5.0]))
+            vup = (0.0, 1.0, 0.0) if case % 3 else tuple(rng.normal(0, 1, 3))
+            focus = float(rng.uniform(0.2, 2.5) * np.linalg.norm(look_from - look_at))
+            cam = initCamera(point(*look_from), point(*look_at), vec3(*vup), vfov=float(rng.uniform(8, 110)), aspectRatio=W / H,
+                             aperture=float(rng.choice([0.0, 0.1, 1.0, 4.0])), focusDist=focus)
+            r.setCamera(cam)
+            spp = int(rng.choice([1, 7, 64, 130]))
+            got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+            st = r.stats()
+            assert st["camera_screen"] == _lib.SCREEN_INTERVAL, case
+            monkeypatch.setenv("RTOW_NO_SLAB_TEST", "1")
+            plain = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+            monkeypatch.delenv("RTOW_NO_SLAB_TEST")
+            assert r.stats()["camera_screen"] == _lib.SCREEN_NONE
+            assert (got[2] == plain[2]).all(), (case, int((got[2] != plain[2]).sum()))
+            assert (got[1] == plain[1]).all() and (got[0] == plain[0]).all(), case
+            assert st["ray_segments"] == r.stats()["ray_segments"], case
+
+
 def test_optional_bundle_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
     """RTOW_CAMERA_SCREEN=bundle (an option for measurements, never the default: it decides about a sphere once per
     wave, not once per ray) puts a test of the table against the wave's 64 camera rays as a whole in front of the
