@@ -173,6 +173,13 @@ def main():
         sock.bind(("127.0.0.1", 0))
         os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]))
         sock.close()
+    # stdout carries ONE line, the result.  Libraries write there too (RCCL prints a version banner on rank 0 when its
+    # first communicator is built), so for the length of the run file descriptor 1 points at stderr and the result
+    # line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -433,7 +440,8 @@ def main():
         }
         if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, depth, seed)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     for r in renderers:
         r.close()
