@@ -586,7 +586,15 @@ static int set_camera_f64(rtow_ctx* c, const rtow_camera_f64& cam) {
   c->have_camera = true;
   c->samples_done = 0;              // accumulated samples belong to the previous camera: no pass may continue them
   c->last_row_list_valid = false;
-  return refresh_spans(c);
+  try {   // refresh_spans stages its tables in host vectors: no exception may leave through the C boundary
+    return refresh_spans(c);
+  } catch (const std::bad_alloc&) {
+    c->spans_valid = false;         // the camera itself is set; its rays see the slab test
+    return fail(RTOW_ERR_NOMEM, "rtow_set_camera: out of host memory for the interval test's tables");
+  } catch (...) {
+    c->spans_valid = false;
+    return fail(RTOW_ERR_INVALID, "rtow_set_camera: unexpected exception");
+  }
 }
 
 int rtow_set_camera_f64(rtow_ctx* c, const rtow_camera_f64* cam) {
