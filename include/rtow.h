@@ -164,7 +164,13 @@ int rtow_set_hittables(rtow_ctx* ctx, int n, const uint8_t* hittable_kind, const
                        const double* center_y, const double* center_z, const double* radius,
                        const uint8_t* material_kind, const double* albedo_rgb, const double* fuzz, const double* ir);
 
-/* Upload the camera (camera.nim:4-10): binary32 fields (widened exactly) or the binary64 ones. */
+/* Upload the camera (camera.nim:4-10): binary32 fields (widened exactly) or the binary64 ones.
+ * Once scene and camera are both known - in either order, and again whenever one of them changes - the library works
+ * out on the host, in O(n), the ranges of the image coordinates in which each sphere can be met by a camera ray (the
+ * tables of RTOW_SCREEN_INTERVAL; it waits for the context's stream first).  That construction covers the camera
+ * initCamera builds (camera.nim:12-31: u, v orthonormal, horizontal and vertical along them, the focus plane
+ * perpendicular to u x v, in binary64); with any other eight vectors - which are accepted as before - the camera
+ * rays get RTOW_SCREEN_SLAB.  Images do not depend on which. */
 int rtow_set_camera(rtow_ctx* ctx, const rtow_camera* cam);
 int rtow_set_camera_f64(rtow_ctx* ctx, const rtow_camera_f64* cam);
 
