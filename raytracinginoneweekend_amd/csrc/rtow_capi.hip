@@ -473,7 +473,8 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   std::vector<rtow::BigSphere> big;
   for (int j = 0; j < n_alloc; ++j) geom_at(j, 3) = INFINITY;
   std::vector<float4> exact((size_t)n_alloc, make_float4(0.f, 0.f, 0.f, 0.f));
-  std::vector<float> nk((size_t)n_alloc, -INFINITY);
+  // (-k is also streamed through LDS in tiles of 256 entries by tables that do not fit there: whole tiles, and one more)
+  std::vector<float> nk(((size_t)n_alloc + 255) / 256 * 256 + 256, -INFINITY);
   // the scene as given, for the binary64 tests of primary rays; every other table holds binary32 roundings
   std::vector<double4> geom64((size_t)(n > 0 ? n : 1), make_double4(0.0, 0.0, 0.0, 1.0));
   float cmax = 0.0f;

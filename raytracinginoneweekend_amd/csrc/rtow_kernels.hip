@@ -239,21 +239,24 @@ static __device__ __forceinline__ f2v pair_filter(const f2v cx, const f2v cy, co
 typedef unsigned long long __attribute__((address_space(3)))* lds_u64_ptr;
 typedef uint32_t __attribute__((address_space(3)))* lds_u32_ptr;
 typedef const double __attribute__((address_space(3)))* lds_f64_ptr;
-constexpr uint32_t kListEntries = 512;   // per wave; drained when fewer than 256 (one group, all lanes) are free
+// entries of a wave's survivor list; it is drained when fewer than 256 (one group, all lanes) are free.  Tables that do
+// not fit LDS use 32-bit entries and fewer of them: their workgroups also hold the rings of scan_tiled, and five
+// workgroups per CU must stay within 32 000 bytes of LDS each.
+constexpr uint32_t kListEntriesShort = 512, kListEntriesLong = 352;
 
 // An entry of the survivor list is (owner lane, list index).  Tables small enough to sit in LDS
 // entirely (<= kMaxSpheresExactInLds entries) use 16-bit entries - the list then takes 1 KB per wave
 // instead of 2 KB, which is what lets five workgroups per CU keep their tables in LDS.
 template <bool SHORT> struct ListEntry;
-template <> struct ListEntry<true> { typedef uint16_t type; static constexpr uint32_t kShift = 10; };
-template <> struct ListEntry<false> { typedef uint32_t type; static constexpr uint32_t kShift = 26; };
+template <> struct ListEntry<true> { typedef uint16_t type; static constexpr uint32_t kShift = 10; static constexpr uint32_t kEntries = kListEntriesShort; };
+template <> struct ListEntry<false> { typedef uint32_t type; static constexpr uint32_t kShift = 26; static constexpr uint32_t kEntries = kListEntriesLong; };
 static_assert(kMaxSpheresExactInLds + 16 <= (1 << ListEntry<true>::kShift), "list index must fit beside the lane number");
 static_assert(kMaxSpheres + 16 <= (1 << ListEntry<false>::kShift), "list index must fit beside the lane number");
 
 // per-wave LDS, in dwords: survivor list, 64 closest-hit keys (8 bytes), 64 closest-hit indices (primary
 // segments), the path pool, the cache of pixel sums
 template <bool SHORT> struct WaveLds {
-  static constexpr uint32_t kList = SHORT ? kListEntries / 2 : kListEntries;
+  static constexpr uint32_t kList = SHORT ? kListEntriesShort / 2 : kListEntriesLong;
   static constexpr uint32_t kKeys = kList;            // 128 dwords
   static constexpr uint32_t kIds = kKeys + 128;       // 64 dwords
   static constexpr uint32_t kPool = kIds + 64;        // kPoolFields * 64 dwords, 8-byte aligned
@@ -274,7 +277,7 @@ struct PrimaryCtx {
 template <bool SHORT>
 struct CandList {
   typedef typename ListEntry<SHORT>::type entry_t;
-  entry_t* list;      // LDS: kListEntries entries of this wave
+  entry_t* list;      // LDS: ListEntry<SHORT>::kEntries entries of this wave
   lds_u64_ptr best;   // LDS: 64 words of this wave, lane L's closest hit so far (hit_key, or the bits of a binary64 t)
   uint32_t n;         // wave-uniform: entries in the list
   uint32_t lane;
@@ -505,7 +508,7 @@ static __device__ __forceinline__ void group_test(const GroupRec grp, f4v nk, nk
     cand_push(cand, f0.y >= r.ozt.y, j + 1);
     cand_push(cand, f1.x >= r.ozt.y, j + 2);
     cand_push(cand, f1.y >= r.ozt.y, j + 3);
-    if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    if (cand.n > ListEntry<SHORT>::kEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
   }
 }
 
@@ -539,14 +542,69 @@ static __device__ __forceinline__ void pair_step(geom_ptr geom, int g, nk_lds_pt
       cand_push(cand, a0.y >= r.ozt.y, j + 1);
       cand_push(cand, a1.x >= r.ozt.y, j + 2);
       cand_push(cand, a1.y >= r.ozt.y, j + 3);
-      if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      if (cand.n > ListEntry<SHORT>::kEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
     }
     cand_push(cand, b0.x >= r.ozt.y, j + 4);
     cand_push(cand, b0.y >= r.ozt.y, j + 5);
     cand_push(cand, b1.x >= r.ozt.y, j + 6);
     cand_push(cand, b1.y >= r.ozt.y, j + 7);
-    if (cand.n > kListEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    if (cand.n > ListEntry<SHORT>::kEntries - 256u) cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
   }
+}
+
+// Tables beyond kMaxSpheresKInLds entries: -k does not fit LDS as a whole, and taken from scalar registers it costs a
+// packed add per pair of spheres (pair_filter<K_SGPR>).  Each WAVE therefore streams -k through a small ring of its
+// own in LDS: tiles of kTileGroups groups (256 spheres, 1 KB), written by global_load_lds - a load that goes from
+// memory to LDS without passing through registers, 16 bytes per lane - one tile ahead of the scan, so
+// that the filter can take -k as the addend of its first FMA exactly as small tables do.  A tile costs one load and a
+// handful of instructions against 128 packed adds.  The ring is private to the wave: no barrier, just the wave's own
+// wait for its load.  The centres keep coming through scalar registers, as always.
+constexpr int kTileGroups = 64;
+constexpr int kRingF4 = 2 * kTileGroups + 2;   // two tiles + the two groups a trip reads ahead past a tile's end
+
+template <bool PRIMARY, bool SHORT, typename ExactPtr>
+static __device__ __forceinline__ void scan_tiled(geom_ptr geom, ExactPtr exact, const f4v* ring, CandList<SHORT>& cand,
+                                                  int n_groups, const ScanRay& r, f3 o, f3 u, float tmin, int prev,
+                                                  const PrimaryCtx& pc RTOW_PROF_PARAM) {
+  typedef const float __attribute__((address_space(1)))* global_f32_ptr;
+  typedef f4v __attribute__((address_space(3)))* ring_ptr;
+  const global_f32_ptr nk_global = (global_f32_ptr)(uintptr_t)KARG(geom_nk);   // -k per list entry, padded to whole tiles + one
+  const ring_ptr ring_lds = (ring_ptr)(f4v*)ring;
+  const int n_tiles = (n_groups + kTileGroups - 1) / kTileGroups;
+  // tile t -> half (t & 1) of the ring; the data is in LDS once the wave's VMEM counter has drained
+  // (one load of 16 bytes by all 64 lanes: a branch on the lane number around a narrower load makes the compiler treat
+  // the whole tile loop as divergent, and every such load costs the wave some hundred cycles to issue whatever its size)
+  auto request = [&](int t) {
+    __builtin_amdgcn_global_load_lds(nk_global + (size_t)t * (4 * kTileGroups) + 4 * cand.lane, ring_lds + (t & 1) * kTileGroups, 16, 0, 0);
+  };
+  request(0);
+  f4v ka = {0, 0, 0, 0}, kb = ka, unused = ka;
+  GroupRec ga = load_group<true, false>(geom, 0, unused, nullptr);   // the first 12 floats of a record: the centres
+  GroupRec gb = load_group<true, false>(geom, 1, unused, nullptr);
+  for (int t = 0; t < n_tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t has landed (and whatever the exact tests had in flight)
+    if (t + 1 < n_tiles) request(t + 1);               // into the half the scan of tile t - 1 has finished with
+    // the LDS address of the tile's -k in a VGPR, so that the reads of a trip use immediate offsets (see scan_regular)
+    uint32_t nk_addr = (uint32_t)(uintptr_t)(nk_lds_ptr)(ring + (t & 1) * kTileGroups);
+    asm volatile("" : "+v"(nk_addr));
+    nk_lds_ptr nk = (nk_lds_ptr)(uintptr_t)nk_addr;
+    ka = nk[0];   // a trip ends by reading two groups past itself: at a tile's end that was not this tile's data
+    kb = nk[1];
+    const int end = min(n_groups, (t + 1) * kTileGroups);
+    int g = t * kTileGroups;
+    for (; g + 8 <= end; g += 8) {
+      pair_step<PRIMARY, true, 0>(geom, g, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      pair_step<PRIMARY, true, 2>(geom, g + 2, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      pair_step<PRIMARY, true, 4>(geom, g + 4, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      pair_step<PRIMARY, true, 6>(geom, g + 6, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      nk += 8;
+    }
+    for (; g < end; g += 2) {
+      pair_step<PRIMARY, true, 0>(geom, g, nk, ga, gb, ka, kb, exact, cand, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+      nk += 2;
+    }
+  }
+  cand_drain<PRIMARY>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
 }
 
 // n_groups is even and the table holds two more (all-padding) groups after the last one, so the
@@ -581,6 +639,12 @@ static __device__ __forceinline__ void scan_regular(geom_ptr geom, ExactPtr exac
   constexpr bool NK_LATE = SLAB && K_LDS;
   f4v ka = (K_LDS && !NK_LATE) ? nk[0] : f4v{0, 0, 0, 0}, kb = ka;
   GroupRec ga = load_group<K_LDS, SLAB>(geom, 0, ka, slab);
+#ifndef RTOW_NO_TILED_K
+  if constexpr (!SLAB && !K_LDS) {   // nk_lds is this wave's ring here (see scan_tiled)
+    scan_tiled<PRIMARY>(geom, exact, nk_lds, cand, n_groups, r, o, u, tmin, prev, pc RTOW_PROF_ARG);
+    return;
+  }
+#endif
 #ifndef RTOW_NO_PAIRED_GROUPS
   if (!SLAB) {
     // Scans without the slab test decide about EIGHT spheres with one compare and one branch (pair_step), and the
@@ -850,7 +914,7 @@ static __device__ __forceinline__ void scan_sparse(ExactPtr exact, const f4v* nk
       if (m != 0) {
         if (pass) cand.list[cand.n + lanes_below(m)] = (typename CandList<SHORT>::entry_t)(((uint32_t)owner << ListEntry<SHORT>::kShift) | (uint32_t)j);
         cand.n += (uint32_t)__popcll(m);
-        if (cand.n > kListEntries - 64u) cand_drain<false>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
+        if (cand.n > ListEntry<SHORT>::kEntries - 64u) cand_drain<false>(cand, exact, o, u, tmin, prev, pc RTOW_PROF_ARG);
       }
     }
   }
@@ -971,7 +1035,11 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
   extern __shared__ f4v lds_raw[];
   typedef WaveLds<X_LDS> L;
   uint32_t* const wave_lds = (uint32_t*)lds_raw + (threadIdx.x >> 6) * L::kTotal;
-  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * L::kTotal / 4;
+  // behind the waves' regions: -k of the whole table (K_LDS), or one ring of tiles of -k per wave (scan_tiled)
+  // (the wave's number as a scalar: the LDS address of a global_load_lds must be wave-uniform, and the compiler cannot see
+  // that threadIdx.x >> 6 is)
+  const f4v* const nk_lds = lds_raw + (kTraceThreads / 64) * L::kTotal / 4 +
+                            (K_LDS ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (uint32_t)kRingF4);
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t* const pool = wave_lds + L::kPool;
   const geom_ptr geom = (geom_ptr)(uintptr_t)P.geom;
@@ -1440,6 +1508,7 @@ __global__ void __launch_bounds__(256) rtow_resolve_kernel(const unsigned long l
 static size_t wave_lds_bytes(bool short_entries) {
   return sizeof(uint32_t) * (kTraceThreads / 64) * (short_entries ? WaveLds<true>::kTotal : WaveLds<false>::kTotal);
 }
+static size_t ring_lds_bytes() { return wave_lds_bytes(false) + sizeof(float4) * (size_t)kRingF4 * (kTraceThreads / 64); }   // scan_tiled's rings
 static size_t k_lds_bytes(int n_geom_pad) { return wave_lds_bytes(false) + sizeof(float) * (size_t)(n_geom_pad + 8); }
 static size_t kx_lds_bytes(int n_geom_pad) {
   return wave_lds_bytes(true) + sizeof(float) * (size_t)(n_geom_pad + 8) + sizeof(float4) * (size_t)n_geom_pad;
@@ -1454,7 +1523,7 @@ static void launch_trace_axis(const TraceParams& p, int grid_blocks, hipStream_t
     hipLaunchKernelGGL((rtow_trace_kernel<true, false, SLAB_AXIS>), dim3(grid_blocks), dim3(kTraceThreads), k_lds_bytes(p.n_geom_pad),
                        stream, p);
   else
-    hipLaunchKernelGGL((rtow_trace_kernel<false, false, SLAB_AXIS>), dim3(grid_blocks), dim3(kTraceThreads), wave_lds_bytes(false), stream, p);
+    hipLaunchKernelGGL((rtow_trace_kernel<false, false, SLAB_AXIS>), dim3(grid_blocks), dim3(kTraceThreads), ring_lds_bytes(), stream, p);
 }
 
 void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStream_t stream) {
@@ -1825,7 +1894,7 @@ int trace_blocks_per_cu(int n_geom_pad) {
   else if (n_geom_pad <= kMaxSpheresKInLds)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<true, false, 1>, kTraceThreads, k_lds_bytes(n_geom_pad));
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false, false, 1>, kTraceThreads, wave_lds_bytes(false));
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtow_trace_kernel<false, false, 1>, kTraceThreads, ring_lds_bytes());
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
