@@ -11,7 +11,7 @@ constexpr int kMaxSpheres = (1 << 26) - 16;   // list indices travel in 26 bits 
 constexpr int kPoolFields = 14;      // per-wave pool, dwords per lane: 64 scattered paths (o, d, throughput, stream, pixel, sphere)
                                      // or, during a primary scan, the 64 camera rays in binary64 (o, d, |d|^2)
 constexpr int kMaxSpheresExactInLds = 512; // up to this many entries the exact-test records sit in LDS too (8 KB)
-constexpr int kMaxSpheresKInLds = 4096;  // up to this many table entries the filter reads -k from LDS (16 KB)          // the regular sphere table is padded to a multiple of this
+constexpr int kMaxSpheresKInLds = 2048;  // up to this many table entries the filter reads -k from an LDS copy of the whole table (8 KB)          // the regular sphere table is padded to a multiple of this
 
 struct TraceParams {
   CameraParams64 cam;        // must stay first: the kernel reads it straight from its argument segment

@@ -9,10 +9,13 @@ ap.add_argument("--spp", type=int, default=125)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--workload", default="C2")
 ap.add_argument("--share", type=int, default=1, help="render only rank 0's row tiles of an N-way split")
+ap.add_argument("--half-extent", type=int, default=0, help="randomScene(halfExtent=...) instead of a named workload (11 = 484 spheres, 50 = 10 001)")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 scene = {"C2": lambda: R.randomScene(), "C3": lambda: R.randomScene(lambertBelow=0.0, metalBelow=0.5),
          "C5": lambda: R.randomScene(halfExtent=50)}[a.workload]()
+if a.half_extent:
+    scene = R.randomScene(halfExtent=a.half_extent)
 n = len(scene)
 scene = scene.flatten()
 scene.pop("hittable_kind")   # builds from before rtow_set_hittables take the plain sphere arrays

@@ -651,7 +651,7 @@ def test_large_tables_and_material_variants(oracle):
     W, H, spp = 72, 48, 3
     with R.Renderer(0) as r:
         r.setCamera(R.bookCamera(W / H))
-        for kw, okw in (({"halfExtent": 35}, {"half_extent": 35}),                      # 4 8xx spheres > 4096
+        for kw, okw in (({"halfExtent": 35}, {"half_extent": 35}),                      # 4 8xx spheres: beyond the LDS copy of -k
                         ({"halfExtent": 20}, {"half_extent": 20}),
                         ({"lambertBelow": 0.0, "metalBelow": 0.5}, {"lambert_below": 0.0, "metal_below": 0.5})):
             r.setWorld(R.randomScene(**kw))
@@ -665,14 +665,15 @@ def test_large_tables_and_material_variants(oracle):
 
 def test_table_sizes_around_the_lds_thresholds(oracle):
     """The kernel has three instances by table size: all tables in LDS (up to 512 padded entries), -k alone
-    in LDS (up to 4096), everything through scalar loads (beyond).  Lists just below, at and just above both
+    in LDS (up to 2048; larger tables stream it through per-wave rings in tiles of 256 entries), everything else through
+    scalar loads.  Lists just below, at and just above both
     thresholds - a ground sphere first, so the binary64 list is non-empty - bit-exact against the mirror."""
     R = _R()
     W, H, spp = 56, 40, 2
     rng = np.random.default_rng(77)
     with R.Renderer(0) as r:
         r.setCamera(R.bookCamera(W / H))
-        for n in (503, 504, 505, 511, 512, 513, 520, 4087, 4088, 4089, 4096, 4097, 4105):
+        for n in (503, 504, 505, 511, 512, 513, 520, 2039, 2040, 2041, 2048, 2049, 2057, 2297, 2305, 2561, 4097):
             center = np.column_stack([rng.uniform(-11, 11, n), np.full(n, 0.2), rng.uniform(-11, 11, n)])
             radius = np.full(n, 0.2)
             center[0], radius[0] = (0.0, -1000.0, 0.0), 1000.0
