@@ -305,6 +305,19 @@ int rtow_render_multi(rtow_ctx* const* ctxs, int n_ctx, int w, int h, int spp, i
 int rtow_multi_plan(int w, int h, int n_ctx, int tile_rows, int32_t* ctx_of_row, int32_t* index_in_ctx,
                     int32_t* rows_per_ctx, uint64_t* slot_bytes);
 
+/* The ranges behind RTOW_SCREEN_INTERVAL as plain arithmetic (no device is touched; nothing in the reference
+ * corresponds to it): for a camera and n spheres, mid_s[i] +- half_s[i] is the range of getRay's first argument s
+ * (camera.nim:34) outside which no camera ray - whatever its t and its point on the lens - can meet sphere i, and
+ * mid_t[i] +- half_t[i] the same for t; widened for the renderer's binary32 comparison |mid - s| <= half.  half = +inf:
+ * any value (the sphere reaches across the lens plane); half < 0: no camera ray can meet the sphere (it lies wholly
+ * behind the lens) or the sphere is not part of the test (|radius| >= 100: every ray tests those anyway).
+ * *covered = 0 when the camera is not one the construction covers (see rtow_set_camera_f64); the arrays are then left
+ * alone.  The renderer compares against the largest half width of a sphere's group of four list entries.  For hosts
+ * that want the bounds for their own use, and for tests.  Any output may be NULL. */
+int rtow_interval_plan(const rtow_camera_f64* cam, int n, const double* center_x, const double* center_y,
+                       const double* center_z, const double* radius, float* mid_s, float* half_s, float* mid_t,
+                       float* half_t, int* covered);
+
 /* The PPM file of the most recent render on this context, as the reference writes it: the header
  * "P3\n{w} {rows}\n255\n" (raytracer.nim:35) followed by one "r g b\n" line per pixel
  * (writeColor, raytracer.nim:28), rows in the order they were rendered.  The text is composed on the

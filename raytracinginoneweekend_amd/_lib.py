@@ -49,7 +49,7 @@ class Stats(C.Structure):
 # every symbol include/rtow.h declares
 SYMBOLS = ["rtow_last_error", "rtow_version", "rtow_device_count", "rtow_create", "rtow_destroy",
            "rtow_set_scene", "rtow_set_scene_f64", "rtow_set_hittables", "rtow_set_camera", "rtow_set_camera_f64", "rtow_render", "rtow_render_async", "rtow_sync",
-           "rtow_render_multi", "rtow_multi_plan", "rtow_trace_rays", "rtow_get_rays", "rtow_scatter_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
+           "rtow_render_multi", "rtow_multi_plan", "rtow_interval_plan", "rtow_trace_rays", "rtow_get_rays", "rtow_scatter_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
 
 _lib = None
 
@@ -119,6 +119,8 @@ def load(path, strict=True):
     L.rtow_set_scene_f64.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtow_set_hittables.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtow_multi_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(C.c_uint64)]
+    if hasattr(L, "rtow_interval_plan"):
+        L.rtow_interval_plan.argtypes = [C.POINTER(CameraStruct64), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.rtow_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     L.rtow_set_camera_f64.argtypes = [vp, C.POINTER(CameraStruct64)]
     L.rtow_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp, vp, vp]

@@ -313,67 +313,86 @@ int rtow_destroy(rtow_ctx* c) {
 // The construction needs the camera the reference builds (camera.nim:12-31): u, v orthonormal, hor and ver along
 // them, the focus plane perpendicular to u x v and in front of the lens.  Any other set of eight vectors the ABI
 // accepts leaves spans_valid false, and the camera rays see the slab test instead.
+// The camera as the construction needs it, or covered = false.
+struct SpanCamera {
+  bool covered = false;
+  double hu = 0, hv = 0, f = 0, R = 0;   // lengths of the focus plane's edges, focus distance, lens radius
+  double w[3] = {0, 0, 0};               // u x v: the direction the camera looks away from
+};
+
+static double dot3d(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static SpanCamera span_camera(const rtow::CameraParams64& cam) {
+  SpanCamera s;
+  s.hu = std::sqrt(dot3d(cam.hor, cam.hor));
+  s.hv = std::sqrt(dot3d(cam.ver, cam.ver));
+  s.w[0] = cam.u[1] * cam.v[2] - cam.u[2] * cam.v[1];
+  s.w[1] = cam.u[2] * cam.v[0] - cam.u[0] * cam.v[2];
+  s.w[2] = cam.u[0] * cam.v[1] - cam.u[1] * cam.v[0];
+  double F[3];
+  for (int k = 0; k < 3; ++k) F[k] = cam.origin[k] - 0.5 * cam.hor[k] - 0.5 * cam.ver[k] - cam.llc[k];   // = f w
+  s.f = dot3d(F, s.w);
+  s.R = cam.lens_radius;
+  bool regular = std::isfinite(s.hu) && std::isfinite(s.hv) && s.hu > 0.0 && s.hv > 0.0 && std::isfinite(s.f) && s.f > 0.0 &&
+                 std::isfinite(s.R) && s.R >= 0.0 && std::fabs(dot3d(cam.u, cam.u) - 1.0) < 1e-9 &&
+                 std::fabs(dot3d(cam.v, cam.v) - 1.0) < 1e-9 && std::fabs(dot3d(cam.u, cam.v)) < 1e-9;
+  for (int k = 0; k < 3 && regular; ++k)
+    regular = std::fabs(cam.hor[k] - s.hu * cam.u[k]) <= 1e-9 * s.hu && std::fabs(cam.ver[k] - s.hv * cam.v[k]) <= 1e-9 * s.hv &&
+              std::fabs(F[k] - s.f * s.w[k]) <= 1e-9 * (s.f + s.hu + s.hv) && std::isfinite(cam.origin[k]);
+  s.covered = regular;
+  return s;
+}
+
+// One sphere's range along one image axis (0: s, across the image; 1: t, up the image) as middle and half width;
+// half = +inf: any value, half < 0: no camera ray can meet the sphere.
+constexpr float kSpanNever = 1e30f;   // the middle of a sphere no ray can meet (and of the padding)
+static void span_of_sphere(const rtow::CameraParams64& cam, const SpanCamera& sc, int axis, double4 sp, float& mid, float& half) {
+  const double* across = axis == 0 ? cam.u : cam.v;   // the image axis the range is measured along
+  const double extent = axis == 0 ? sc.hu : sc.hv;   // length of the focus plane's edge along it
+  const double Rl = sc.R * (1.0 + 1e-9);
+  const double rel[3] = {sp.x - cam.origin[0], sp.y - cam.origin[1], sp.z - cam.origin[2]};
+  const double X = dot3d(rel, across), Z = -dot3d(rel, sc.w);
+  // The camera's vectors may be off the ideal frame by 1e-9 of their lengths (span_camera), and the ray and this
+  // arithmetic round in binary64: lens and focus points then sit within 1e-9 (hu + hv + f + R) of where the
+  // construction puts them, which moves a line by up to (1 + Z / f) times that at the sphere's depth.
+  const double rho = std::fabs(sp.w) * (1.0 + 1e-9) + 4e-9 * (sc.hu + sc.hv + sc.f + Rl + std::fabs(X) + std::fabs(Z)) * (1.0 + std::fabs(Z) / sc.f);
+  mid = kSpanNever; half = -1.0f;
+  if (Z < -rho) return;                        // wholly behind the lens line: never
+  mid = 0.0f; half = INFINITY;
+  if (!(Z > rho * (1.0 + 1e-6))) return;       // reaches across the lens line: any value
+  const double k = Z * Z - rho * rho;
+  double s_lo = INFINITY, s_hi = -INFINITY;
+  for (int e = 0; e < 2; ++e) {
+    const double xl = e ? Rl : -Rl, A = X - xl, root = rho * std::sqrt(A * A + k);
+    s_lo = std::min(s_lo, (xl + sc.f * (A * Z - root) / k) / extent + 0.5);
+    s_hi = std::max(s_hi, (xl + sc.f * (A * Z + root) / k) / extent + 0.5);
+  }
+  if (!std::isfinite(s_lo) || !std::isfinite(s_hi)) return;
+  const double pad = 0x1p-19 * (std::fabs(s_lo) + std::fabs(s_hi) + 2.0);
+  const float m = (float)(0.5 * (s_lo + s_hi));
+  if (!std::isfinite(m) || std::fabs(m) >= kSpanNever) return;
+  mid = m;
+  // half width against the ROUNDED middle, rounded up
+  half = std::nextafter((float)(std::max(s_hi - (double)m, (double)m - s_lo) + pad), INFINITY);
+}
+
 static int refresh_spans(rtow_ctx* c) {
   c->spans_valid = false;
   if (!c->have_scene || !c->have_camera) return RTOW_OK;
-  const rtow::CameraParams64& cam = c->cam;
-  auto dot = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-  const double hu = std::sqrt(dot(cam.hor, cam.hor)), hv = std::sqrt(dot(cam.ver, cam.ver));
-  const double w[3] = {cam.u[1] * cam.v[2] - cam.u[2] * cam.v[1], cam.u[2] * cam.v[0] - cam.u[0] * cam.v[2],
-                       cam.u[0] * cam.v[1] - cam.u[1] * cam.v[0]};   // u x v: the direction the camera looks away from
-  double F[3];
-  for (int k = 0; k < 3; ++k) F[k] = cam.origin[k] - 0.5 * cam.hor[k] - 0.5 * cam.ver[k] - cam.llc[k];   // = f w
-  const double f = dot(F, w);
-  const double R = cam.lens_radius;
-  bool regular = std::isfinite(hu) && std::isfinite(hv) && hu > 0.0 && hv > 0.0 && std::isfinite(f) && f > 0.0 &&
-                 std::isfinite(R) && R >= 0.0 && std::fabs(dot(cam.u, cam.u) - 1.0) < 1e-9 &&
-                 std::fabs(dot(cam.v, cam.v) - 1.0) < 1e-9 && std::fabs(dot(cam.u, cam.v)) < 1e-9;
-  for (int k = 0; k < 3 && regular; ++k)
-    regular = std::fabs(cam.hor[k] - hu * cam.u[k]) <= 1e-9 * hu && std::fabs(cam.ver[k] - hv * cam.v[k]) <= 1e-9 * hv &&
-              std::fabs(F[k] - f * w[k]) <= 1e-9 * (f + hu + hv) && std::isfinite(cam.origin[k]);
-  if (!regular) return RTOW_OK;
+  const SpanCamera sc = span_camera(c->cam);
+  if (!sc.covered) return RTOW_OK;
 
   const int n = c->n_spheres, n_alloc = c->n_geom_pad + 4 * rtow::kSpanPadGroups;   // padding: see scan_interval
-  const float kNever = 1e30f;
-  // the same construction along the image's other axis (drop u instead of v) bounds the second argument of getRay, t
-  c->host_span_mid.assign((size_t)n_alloc * 2, kNever);
+  // per list entry the middle, per group of four the largest half width; the ranges of s, then those of t
+  c->host_span_mid.assign((size_t)n_alloc * 2, kSpanNever);
   c->host_span_half.assign((size_t)(n_alloc / 4) * 2, -1.0f);
-  const double Rl = R * (1.0 + 1e-9);
   for (int axis = 0; axis < 2; ++axis) {
-    const double* across = axis == 0 ? cam.u : cam.v;   // the image axis the range is measured along
-    const double extent = axis == 0 ? hu : hv;         // length of the focus plane's edge along it
     float* const mids = c->host_span_mid.data() + (size_t)axis * (size_t)n_alloc;
     float* const halves = c->host_span_half.data() + (size_t)axis * (size_t)(n_alloc / 4);
     for (int j = 0; j < n; ++j) {
       if (!c->host_regular[(size_t)j]) continue;   // the |radius| >= kBigRadius spheres are tested by every ray anyway
-      const double4 sp = c->host_geom64[(size_t)j];
-      const double rel[3] = {sp.x - cam.origin[0], sp.y - cam.origin[1], sp.z - cam.origin[2]};
-      const double X = dot(rel, across), Z = -dot(rel, w);
-      // The camera's vectors may be off the ideal frame by 1e-9 of their lengths (the check above), and the ray and this
-      // arithmetic round in binary64: lens and focus points then sit within 1e-9 (hu + hv + f + R) of where the
-      // construction puts them, which moves a line by up to (1 + Z / f) times that at the sphere's depth.
-      const double rho = std::fabs(sp.w) * (1.0 + 1e-9) + 4e-9 * (hu + hv + f + Rl + std::fabs(X) + std::fabs(Z)) * (1.0 + std::fabs(Z) / f);
       float mid, half;
-      if (Z < -rho) continue;                      // wholly behind the lens line: never
-      if (!(Z > rho * (1.0 + 1e-6))) {             // reaches across the lens line: any value
-        mid = 0.0f; half = INFINITY;
-      } else {
-        const double k = Z * Z - rho * rho;
-        double s_lo = INFINITY, s_hi = -INFINITY;
-        for (int e = 0; e < 2; ++e) {
-          const double xl = e ? Rl : -Rl, A = X - xl, root = rho * std::sqrt(A * A + k);
-          s_lo = std::min(s_lo, (xl + f * (A * Z - root) / k) / extent + 0.5);
-          s_hi = std::max(s_hi, (xl + f * (A * Z + root) / k) / extent + 0.5);
-        }
-        if (!std::isfinite(s_lo) || !std::isfinite(s_hi)) { mid = 0.0f; half = INFINITY; }
-        else {
-          const double pad = 0x1p-19 * (std::fabs(s_lo) + std::fabs(s_hi) + 2.0);
-          mid = (float)(0.5 * (s_lo + s_hi));
-          // half width against the ROUNDED middle, rounded up
-          half = std::nextafter((float)(std::max(s_hi - (double)mid, (double)mid - s_lo) + pad), INFINITY);
-          if (!std::isfinite(mid) || std::fabs(mid) >= kNever) { mid = 0.0f; half = INFINITY; }
-        }
-      }
+      span_of_sphere(c->cam, sc, axis, c->host_geom64[(size_t)j], mid, half);
       mids[(size_t)j] = mid;
       if (half > halves[(size_t)(j / 4)]) halves[(size_t)(j / 4)] = half;
     }
@@ -386,6 +405,35 @@ static int refresh_spans(rtow_ctx* c) {
   c->spans_valid = true;
   return RTOW_OK;
 }
+
+extern "C" {
+
+int rtow_interval_plan(const rtow_camera_f64* cam, int n, const double* cx, const double* cy, const double* cz,
+                       const double* radius, float* mid_s, float* half_s, float* mid_t, float* half_t, int* covered) {
+  if (!cam || n < 0 || (n > 0 && (!cx || !cy || !cz || !radius)))
+    return fail(RTOW_ERR_INVALID, "rtow_interval_plan: NULL argument or n = %d", n);
+  rtow::CameraParams64 c64;
+  for (int k = 0; k < 3; ++k) {
+    c64.origin[k] = cam->origin[k]; c64.llc[k] = cam->lower_left[k]; c64.hor[k] = cam->horizontal[k];
+    c64.ver[k] = cam->vertical[k]; c64.u[k] = cam->u[k]; c64.v[k] = cam->v[k];
+  }
+  c64.lens_radius = cam->lens_radius;
+  const SpanCamera sc = span_camera(c64);
+  if (covered) *covered = sc.covered ? 1 : 0;
+  if (!sc.covered) return RTOW_OK;
+  for (int j = 0; j < n; ++j)
+    for (int axis = 0; axis < 2; ++axis) {
+      float mid = kSpanNever, half = -1.0f;
+      if (std::fabs((float)radius[j]) < rtow::kBigRadius) span_of_sphere(c64, sc, axis, make_double4(cx[j], cy[j], cz[j], radius[j]), mid, half);
+      float* const m = axis == 0 ? mid_s : mid_t;
+      float* const h = axis == 0 ? half_s : half_t;
+      if (m) m[j] = mid;
+      if (h) h[j] = half;
+    }
+  return RTOW_OK;
+}
+
+}  // extern "C"
 
 template <typename T>
 static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T* cz, const T* radius, const uint8_t* kind,

@@ -226,6 +226,22 @@ class Renderer:
         return p.value
 
 
+def intervalPlan(camera, world, lib=None):
+    """rtow_interval_plan: per sphere of `world` the ranges of getRay's arguments s and t in which a camera ray can meet
+    it, as (mid_s, half_s, mid_t, half_t) float32 arrays, or None when the camera is not one the construction covers.
+    Plain host arithmetic: needs no GPU."""
+    L = lib or _lib.lib()
+    flat = world.flatten() if hasattr(world, "flatten") else world
+    cx, cy, cz, rad = (np.ascontiguousarray(flat[k], np.float64) for k in ("center_x", "center_y", "center_z", "radius"))
+    n = len(rad)
+    out = [np.zeros(n, np.float32) for _ in range(4)]
+    covered = C.c_int(0)
+    cam = camera.to_struct() if isinstance(camera, Camera) else camera
+    _lib.check(L.rtow_interval_plan(C.byref(cam), n, cx.ctypes.data, cy.ctypes.data, cz.ctypes.data, rad.ctypes.data,
+                                    out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data, C.byref(covered)))
+    return tuple(out) if covered.value else None
+
+
 def multiPlan(width, height, n_ctx, tile=4, lib=None):
     """The dealing of rows behind renderMulti (rtow_multi_plan; no GPU is touched): returns
     (ctx_of_row int32 [height], index_in_ctx int32 [height], rows_per_ctx int32 [n_ctx], slot_bytes)."""

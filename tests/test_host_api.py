@@ -275,3 +275,74 @@ def test_cpp_host_cli_builds_the_reference_scene(oracle):
                 assert float(v[9]) == s.ir
     bad = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
     assert bad.returncode == 2 and "unknown argument" in bad.stderr
+
+
+def test_interval_plan_of_the_library_is_conservative():
+    """rtow_interval_plan is the host arithmetic behind the renderer's default first test of camera rays (no GPU
+    involved): per sphere the ranges of getRay's arguments (s, t) outside which no camera ray can meet it.  Held here
+    against rays built as camera.nim:34-39 builds them, in binary64 numpy: for random look-at cameras and worlds no
+    ray whose line meets a sphere in front of its origin may have s or t outside that sphere's range as the kernel
+    compares it (binary32 |mid - s| <= half); spheres marked unreachable are met by no forward ray; |radius| >= 100
+    is left out of the test; a sheared camera, a scaled basis and a binary32 camera are reported as not covered."""
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    rng = np.random.default_rng(5)
+    f32 = np.float32
+    checked = 0
+    for trial in range(30):
+        spread = float(rng.choice([3.0, 11.0, 60.0]))
+        n = 200
+        c = np.column_stack([rng.uniform(-spread, spread, n), rng.uniform(-0.2 * spread, 0.4 * spread, n), rng.uniform(-spread, spread, n)])
+        r = rng.choice([0.05, 0.2, 1.0, 4.0], n) * np.exp(rng.uniform(-0.5, 0.5, n)) * rng.choice([1.0, -1.0], n)
+        r[0] = 1000.0; c[0] = (0.0, -1000.0, 0.0)
+        look_from = rng.normal(0, 1, 3) * float(rng.choice([0.3, 1.0, 3.0])) * spread
+        look_at = rng.normal(0, 0.3, 3) * spread
+        vup = (0.0, 1.0, 0.0) if trial % 3 else tuple(rng.normal(0, 1, 3))
+        aspect = float(rng.choice([1.0, 1.5, 16 / 9]))
+        lens = float(rng.choice([0.0, 0.05, 0.5, 2.0]))
+        cam = initCamera(point(*look_from), point(*look_at), vec3(*vup), vfov=float(rng.uniform(10, 100)), aspectRatio=aspect,
+                         aperture=2 * lens, focusDist=float(rng.uniform(0.3, 2.0) * np.linalg.norm(look_from - look_at)))
+        world = {"center_x": c[:, 0], "center_y": c[:, 1], "center_z": c[:, 2], "radius": r}
+        plan = R.intervalPlan(cam, world)
+        assert plan is not None
+        mid_s, half_s, mid_t, half_t = plan
+        assert half_s[0] < 0 and half_t[0] < 0          # the ground sphere takes no part
+        # rays of getRay (camera.nim:34-39)
+        m = 3000
+        s, t = rng.uniform(-0.01, 1.01, m), rng.uniform(-0.01, 1.01, m)
+        ang, rad = rng.uniform(0, 2 * np.pi, m), np.sqrt(rng.uniform(0, 1, m))
+        u, v = np.array(list(cam.u)), np.array(list(cam.v))
+        origin, llc = np.array(list(cam.origin)), np.array(list(cam.lowerLeftCorner))
+        hor, ver = np.array(list(cam.horizontal)), np.array(list(cam.vertical))
+        off = (lens * rad * np.cos(ang))[:, None] * u[None, :] + (lens * rad * np.sin(ang))[:, None] * v[None, :]
+        o = origin[None, :] + off
+        d = llc[None, :] + s[:, None] * hor[None, :] + t[:, None] * ver[None, :] - origin[None, :] - off
+        dn = d / np.linalg.norm(d, axis=1, keepdims=True)
+        oc = c[None, 1:, :] - o[:, None, :]
+        along = np.einsum("mnk,mk->mn", oc, dn)
+        dist = np.linalg.norm(oc - along[:, :, None] * dn[:, None, :], axis=2)
+        rr = np.abs(r[1:])[None, :]
+        forward = (dist <= rr) & (along + np.sqrt(np.maximum(rr ** 2 - dist ** 2, 0.0)) > 0)
+        for mid, half, coord in ((mid_s[1:], half_s[1:], s), (mid_t[1:], half_t[1:], t)):
+            with np.errstate(invalid="ignore"):
+                passes = np.abs(mid[None, :] - coord.astype(f32)[:, None]) <= half[None, :]
+            assert passes[forward].all(), (trial, int((~passes[forward]).sum()))
+        checked += int(forward.sum())
+    assert checked > 10000
+    # cameras the construction does not cover
+    book = R.bookCamera(1.5)
+    sheared = book.to_struct()
+    for k in range(3):
+        sheared.horizontal[k] += 0.2 * sheared.v[k]
+    scaled = book.to_struct()
+    for k in range(3):
+        scaled.u[k] *= 1.5
+    rounded = book.to_struct()
+    for name in ("origin", "lower_left", "horizontal", "vertical", "u", "v", "w"):
+        arr = getattr(rounded, name)
+        for k in range(3):
+            arr[k] = float(np.float32(arr[k]))
+    world = {"center_x": [0.0], "center_y": [0.0], "center_z": [0.0], "radius": [1.0]}
+    assert R.intervalPlan(book, world) is not None
+    for cam in (sheared, scaled, rounded):
+        assert R.intervalPlan(cam, world) is None
