@@ -26,6 +26,8 @@ proc rtow_set_hittables*(ctx: RtowCtx, n: cint, hittableKind: ptr uint8, cx, cy,
 proc rtow_multi_plan*(w, h, nCtx, tileRows: cint, ctxOfRow, indexInCtx, rowsPerCtx: ptr int32,
                       slotBytes: ptr uint64): cint {.importc, dynlib: rtowLib.}
 proc rtow_set_camera_f64*(ctx: RtowCtx, cam: ptr RtowCameraF64): cint {.importc, dynlib: rtowLib.}
+proc rtow_interval_plan*(cam: ptr RtowCameraF64, n: cint, cx, cy, cz, radius: ptr cdouble, midS, halfS, midT, halfT: ptr cfloat,
+                         covered: ptr cint): cint {.importc, dynlib: rtowLib.}
 proc rtow_render*(ctx: RtowCtx, w, h, spp, maxDepth: cint, seed: uint64, rows: ptr int32, nRows: cint,
                   rgbOut: ptr uint8, accumOut: ptr uint64, hitIdOut: ptr int32): cint {.importc, dynlib: rtowLib.}
 proc rtow_render_multi*(ctxs: ptr RtowCtx, nCtx: cint, w, h, spp, maxDepth: cint, seed: uint64, tileRows: cint,
