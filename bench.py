@@ -18,7 +18,10 @@ row tiles and each step ends with the RCCL gather of the 8-bit rows, so total wo
 Prints ONE JSON line on rank 0.  value = ray segments (world.hit queries) of all ranks / wall
 seconds / 1e6.  roofline: algorithmic FLOP (18 per ray-sphere test, 18*N+65 per segment) over
 the trace kernel's own duration, measured with HIP events on the stream it runs on in three
-un-overlapped steps after the timed region (the median of the three).
+un-overlapped steps after the timed region (the median of the three).  The same three steps
+are then repeated with the camera rays' first test switched off (frac_without_first_test),
+with the slab test in its place, and with the optional bundle test; none of those enters
+`value` or `frac`.
 cpu_baseline: the FP64 CPU restatement of the reference (oracle/, "port") timed on this box's
 host cores on a bounded sample of the same frame.
 """
