@@ -928,6 +928,45 @@ def test_random_scenes_bit_exact(oracle):
             assert r.stats()["ray_segments"] == ref[3], f"case {case}: segment count"
 
 
+def test_large_tables_random_worlds(oracle, monkeypatch):
+    """Tables that do not fit LDS stream -k through a ring per wave (tiles of 256 entries written by LDS-DMA loads, one
+    tile ahead of the scan), take the centres through scalar loads and keep 32-bit survivor lists.  Seeded random worlds
+    of 2 049 .. 7 000 spheres - so that tables end anywhere inside a tile - with random cameras, with the default first
+    test of the camera rays and with none (camera rays then go through the same tiled scan): bit for bit the mirror."""
+    from raytracinginoneweekend_amd.basetypes import point, vec3
+    from raytracinginoneweekend_amd.camera import initCamera
+    R = _R()
+    rng = np.random.default_rng(424242)
+    W, H = 64, 40
+    with R.Renderer(0) as r:
+        for case in range(6):
+            n = int(rng.integers(2049, 7001))
+            spread = float(rng.choice([12.0, 30.0]))
+            center = np.column_stack([rng.uniform(-spread, spread, n), rng.uniform(0.0, 1.0, n), rng.uniform(-spread, spread, n)])
+            radius = rng.uniform(0.05, 0.4, n) * rng.choice([1.0, 1.0, -1.0], n)
+            center[0], radius[0] = (0.0, -1000.0, 0.0), 1000.0
+            kind = rng.integers(0, 3, n)
+            albedo, fuzz, ir = rng.uniform(0.0, 1.0, (n, 3)), rng.uniform(0.0, 0.6, n), rng.uniform(1.1, 2.0, n)
+            r.setWorld({"center_x": center[:, 0], "center_y": center[:, 1], "center_z": center[:, 2], "radius": radius,
+                        "kind": kind, "albedo": albedo, "fuzz": fuzz, "ir": ir})
+            arr, k = oracle.spheres_from_arrays(center, radius, kind, albedo, fuzz, ir)
+            look_from = (float(rng.normal(0, spread)), float(rng.uniform(0.3, 8.0)), float(rng.normal(0, spread)))
+            look_at = (float(rng.normal(0, 3)), 0.3, float(rng.normal(0, 3)))
+            vfov, ap, focus = float(rng.uniform(15, 90)), float(rng.choice([0.0, 0.1, 1.0])), float(rng.uniform(2.0, 30.0))
+            r.setCamera(initCamera(point(*look_from), point(*look_at), vec3(0, 1, 0), vfov=vfov, aspectRatio=W / H, aperture=ap, focusDist=focus))
+            cam = oracle.book_camera(W / H, look_from=look_from, look_at=look_at, vfov=vfov, aperture=ap, focus=focus)
+            spp, depth = int(rng.choice([1, 3, 70])), int(rng.choice([1, 50]))
+            ref = oracle.render_mirror32(arr, k, cam, W, H, spp, depth, threads=16)
+            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}):
+                for key, v in env.items():
+                    monkeypatch.setenv(key, v)
+                got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+                for key in env:
+                    monkeypatch.delenv(key)
+                _check_bit_exact(got, ref)
+                assert r.stats()["ray_segments"] == ref[3], (case, n, env)
+
+
 def test_dense_overlap_many_survivors_per_ray(oracle):
     """600 spheres that all overlap around one point, of all three materials and both radius signs: a ray
     through the cluster passes the scan's screen for hundreds of them, so the wave's list of survivors
