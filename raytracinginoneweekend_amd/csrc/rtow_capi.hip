@@ -619,11 +619,15 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
 extern "C" {
 
 static int set_camera_f64(rtow_ctx* c, const rtow_camera_f64& cam) {
+  rtow::CameraParams64 next;
   for (int k = 0; k < 3; ++k) {
-    c->cam.origin[k] = cam.origin[k]; c->cam.llc[k] = cam.lower_left[k]; c->cam.hor[k] = cam.horizontal[k];
-    c->cam.ver[k] = cam.vertical[k]; c->cam.u[k] = cam.u[k]; c->cam.v[k] = cam.v[k];
+    next.origin[k] = cam.origin[k]; next.llc[k] = cam.lower_left[k]; next.hor[k] = cam.horizontal[k];
+    next.ver[k] = cam.vertical[k]; next.u[k] = cam.u[k]; next.v[k] = cam.v[k];
   }
-  c->cam.lens_radius = cam.lens_radius;
+  next.lens_radius = cam.lens_radius;
+  // the same camera again (a host that sets it before every frame): the interval test's tables still match
+  const bool tables_match = c->have_camera && c->spans_valid && std::memcmp(&next, &c->cam, sizeof(next)) == 0;
+  c->cam = next;
   {
     // direction of the ray through the middle of the image; the slab test projects along the axis it has least of
     double d[3], best = INFINITY;
@@ -635,6 +639,7 @@ static int set_camera_f64(rtow_ctx* c, const rtow_camera_f64& cam) {
   c->have_camera = true;
   c->samples_done = 0;              // accumulated samples belong to the previous camera: no pass may continue them
   c->last_row_list_valid = false;
+  if (tables_match) return RTOW_OK;
   try {   // refresh_spans stages its tables in host vectors: no exception may leave through the C boundary
     return refresh_spans(c);
   } catch (const std::bad_alloc&) {

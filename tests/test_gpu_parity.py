@@ -820,6 +820,11 @@ def test_interval_test_on_random_cameras_and_worlds(monkeypatch):
             assert (got[2] == plain[2]).all(), (case, int((got[2] != plain[2]).sum()))
             assert (got[1] == plain[1]).all() and (got[0] == plain[0]).all(), case
             assert st["ray_segments"] == r.stats()["ray_segments"], case
+            if case % 10 == 0:   # the same camera set again keeps the tables; a changed world rebuilds them
+                r.setCamera(cam)
+                again = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+                assert r.stats()["camera_screen"] == _lib.SCREEN_INTERVAL
+                assert (again[1] == got[1]).all() and (again[2] == got[2]).all()
 
 
 def test_optional_bundle_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
