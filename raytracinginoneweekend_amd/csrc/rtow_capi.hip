@@ -719,6 +719,13 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   const uint64_t blocks_needed = (waves_needed + (rtow::kTraceThreads / 64) - 1) / (rtow::kTraceThreads / 64);
   if ((uint64_t)grid > blocks_needed) grid = (int)(blocks_needed ? blocks_needed : 1);
   p.n_waves = (uint32_t)grid * (rtow::kTraceThreads / 64);
+  uint32_t taper = 4;   // chunks shrink once fewer than this many chunks of chunk_max per wave are left
+  if (const char* e = getenv("RTOW_CHUNK_TAPER")) {  // experiments only
+    const int v = atoi(e);
+    if (v >= 1 && v <= 4096) taper = (uint32_t)v;
+  }
+  while (taper > 1 && (uint64_t)taper * p.n_waves * p.chunk_max >= 0x100000000ull) taper /= 2;
+  p.chunk_taper = taper * p.n_waves;
 
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemsetAsync(t.counters, 0, kCounterBytes, c->stream));

@@ -42,6 +42,7 @@ struct TraceParams {
   // paths at a time while plenty is left and down to chunk_min towards the end of the frame, so
   // that the last waves to finish are at most one short chunk behind the others.
   uint32_t chunk_max, chunk_min;    // multiples of 64, chunk_min <= chunk_max
+  uint32_t chunk_taper;             // a chunk is (paths left / chunk_taper) once that is below chunk_max; chunk_taper * chunk_max < 2^32
   uint32_t n_waves;                 // wavefronts in the grid
   uint32_t inv_spp;                 // ceil(2^32 / spp): n / spp == mulhi(n, inv_spp) while n * spp < 2^32
   unsigned long long total_paths;   // n_rows * W * spp

@@ -1139,12 +1139,12 @@ __global__ void __launch_bounds__(kTraceThreads, 5) rtow_trace_kernel(const Trac
     uint32_t n_gen = 0;
     if (__ballot(!alive) != 0 && pool_head >= pool_n) {
       if (e_next >= e_end && !exhausted) {
-        // guided self-scheduling: a quarter of an even share of what was left when this wave
-        // last looked, clamped to [chunk_min, chunk_max] and rounded down to whole wavefronts
+        // guided self-scheduling: a fixed fraction (1 / chunk_taper; a fraction of an even share) of what
+        // was left when this wave last looked, clamped to [chunk_min, chunk_max] and rounded down to whole wavefronts
         uint32_t want = KARG(chunk_max);
         const unsigned long long left_seen = KARG(total_paths) - seen;
-        if (left_seen < 4ull * KARG(n_waves) * KARG(chunk_max)) {
-          want = ((uint32_t)left_seen / (4u * KARG(n_waves))) & ~63u;
+        if (left_seen < (unsigned long long)KARG(chunk_taper) * KARG(chunk_max)) {
+          want = ((uint32_t)left_seen / KARG(chunk_taper)) & ~63u;
           want = want < KARG(chunk_min) ? KARG(chunk_min) : want;
         }
         unsigned long long first = 0;
