@@ -280,6 +280,14 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     segments = sum(st["ray_segments"] for st in stats)
+    if sharded:   # the slowest rank's time, before anything is decided from it: all ranks must take the same branches below
+        red_dev = f"cuda:{device}" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([segments], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        segments = int(s.item())
 
     # one frame at a time, for the kernel's own duration (launches that overlap stretch each other)
     # and for the latency of a single step
@@ -342,15 +350,6 @@ def main():
         last = gatherers[(n_serial - 1) % depth_in_flight].full          # gathered by the last step
         whole = renderers[0].renderRows(width, height, spp, depth, seed)[0]
         image_verified = bool((last.cpu().numpy() == whole).all())
-
-    if sharded:
-        red_dev = f"cuda:{device}" if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([segments], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        segments = int(s.item())
 
     if rank == 0:
         flop_per_segment = FLOP_PER_TEST * n_spheres + FLOP_PER_SEGMENT_EXTRA
