@@ -28,6 +28,8 @@ proc rtow_multi_plan*(w, h, nCtx, tileRows: cint, ctxOfRow, indexInCtx, rowsPerC
 proc rtow_set_camera_f64*(ctx: RtowCtx, cam: ptr RtowCameraF64): cint {.importc, dynlib: rtowLib.}
 proc rtow_interval_plan*(cam: ptr RtowCameraF64, n: cint, cx, cy, cz, radius: ptr cdouble, midS, halfS, midT, halfT: ptr cfloat,
                          covered: ptr cint): cint {.importc, dynlib: rtowLib.}
+proc rtow_mask_plan*(cam: ptr RtowCameraF64, n: cint, cx, cy, cz, radius: ptr cdouble, groupMask: ptr uint32, grid: ptr cfloat,
+                     columns, covered: ptr cint): cint {.importc, dynlib: rtowLib.}
 proc rtow_render*(ctx: RtowCtx, w, h, spp, maxDepth: cint, seed: uint64, rows: ptr int32, nRows: cint,
                   rgbOut: ptr uint8, accumOut: ptr uint64, hitIdOut: ptr int32): cint {.importc, dynlib: rtowLib.}
 proc rtow_render_multi*(ctxs: ptr RtowCtx, nCtx: cint, w, h, spp, maxDepth: cint, seed: uint64, tileRows: cint,

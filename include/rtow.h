@@ -75,10 +75,14 @@ enum {
   RTOW_SCREEN_NONE = 0,      /* nothing: every camera ray puts every sphere through the screen (RTOW_NO_SLAB_TEST) */
   RTOW_SCREEN_SLAB = 1,      /* per (ray, sphere): distance between centre and the ray's line seen along one world axis */
   RTOW_SCREEN_INTERVAL = 2,  /* per (ray, sphere): the ray's image coordinates against the ranges in which the sphere can
-                                be met at all (tables made by the library from scene and camera); the default for the
-                                camera initCamera builds (camera.nim:12-31), other cameras get the slab test */
-  RTOW_SCREEN_BUNDLE = 3     /* per (wave, sphere): the list against a wave's 64 camera rays as one packet; only with
+                                be met at all (tables made by the library from scene and camera), for the camera
+                                initCamera builds (camera.nim:12-31); other cameras get the slab test */
+  RTOW_SCREEN_BUNDLE = 3,    /* per (wave, sphere): the list against a wave's 64 camera rays as one packet; only with
                                 RTOW_CAMERA_SCREEN=bundle - packet culling, not brute force per ray */
+  RTOW_SCREEN_MASK = 4       /* per (ray, group of four spheres): the tile of the image the ray aims at against the tiles
+                                in which the group's spheres can be met (one 32-bit word per group, from the same ranges),
+                                then RTOW_SCREEN_INTERVAL on the groups that pass; the default for frames of at least
+                                16 x 16 pixels with a camera the ranges cover */
 };
 
 /* The eight private fields of Camera (camera.nim:4-10), rounded to binary32 by the host after
@@ -167,7 +171,7 @@ int rtow_set_hittables(rtow_ctx* ctx, int n, const uint8_t* hittable_kind, const
 /* Upload the camera (camera.nim:4-10): binary32 fields (widened exactly) or the binary64 ones.
  * Once scene and camera are both known - in either order, and again whenever one of them changes - the library works
  * out on the host, in O(n), the ranges of the image coordinates in which each sphere can be met by a camera ray (the
- * tables of RTOW_SCREEN_INTERVAL; it waits for the context's stream first).  That construction covers the camera
+ * tables of RTOW_SCREEN_INTERVAL and RTOW_SCREEN_MASK; it waits for the context's stream first).  That construction covers the camera
  * initCamera builds (camera.nim:12-31: u, v orthonormal, horizontal and vertical along them, the focus plane
  * perpendicular to u x v, in binary64); with any other eight vectors - which are accepted as before - the camera
  * rays get RTOW_SCREEN_SLAB.  Images do not depend on which. */
@@ -317,6 +321,17 @@ int rtow_multi_plan(int w, int h, int n_ctx, int tile_rows, int32_t* ctx_of_row,
 int rtow_interval_plan(const rtow_camera_f64* cam, int n, const double* center_x, const double* center_y,
                        const double* center_z, const double* radius, float* mid_s, float* half_s, float* mid_t,
                        float* half_t, int* covered);
+
+/* The words behind RTOW_SCREEN_MASK as plain arithmetic (no device is touched; nothing in the reference corresponds
+ * to it).  The image is cut into *columns x (32 / *columns) tiles; a ray with image coordinates (s, t) - getRay's
+ * arguments, camera.nim:34 - aims at column trunc(med3(s * grid[0] + grid[1], 0, grid[4])) and row
+ * trunc(med3(t * grid[2] + grid[3], 0, grid[5])), all in binary32 with one fused multiply-add, and its bit is
+ * column + *columns * row.  group_mask[g], g < (n + 3) / 4, has the bits of the tiles in which a camera ray can meet
+ * one of the spheres 4g .. 4g+3: a ray whose bit is not set there meets none of them.  Valid for frames at least 16
+ * pixels wide and high (s, t <= 1 + 1/15).  *covered as in rtow_interval_plan.  Any output may be NULL. */
+int rtow_mask_plan(const rtow_camera_f64* cam, int n, const double* center_x, const double* center_y,
+                   const double* center_z, const double* radius, uint32_t* group_mask, float* grid, int* columns,
+                   int* covered);
 
 /* The PPM file of the most recent render on this context, as the reference writes it: the header
  * "P3\n{w} {rows}\n255\n" (raytracer.nim:35) followed by one "r g b\n" line per pixel

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RTOW_LIB_PATH") or os.path.join(_HERE, "lib", "librto
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 HT_SPHERE = 0                                   # HittableKind (hittables.nim:4-5)
 GATHER_NONE, GATHER_HOST, GATHER_RCCL, GATHER_HOST_AFTER_RCCL = 0, 1, 2, 3   # rtow_stats.gather_path
-SCREEN_NONE, SCREEN_SLAB, SCREEN_INTERVAL, SCREEN_BUNDLE = 0, 1, 2, 3          # rtow_stats.camera_screen
+SCREEN_NONE, SCREEN_SLAB, SCREEN_INTERVAL, SCREEN_BUNDLE, SCREEN_MASK = 0, 1, 2, 3, 4          # rtow_stats.camera_screen
 
 
 class RtowError(RuntimeError):
@@ -49,7 +49,7 @@ class Stats(C.Structure):
 # every symbol include/rtow.h declares
 SYMBOLS = ["rtow_last_error", "rtow_version", "rtow_device_count", "rtow_create", "rtow_destroy",
            "rtow_set_scene", "rtow_set_scene_f64", "rtow_set_hittables", "rtow_set_camera", "rtow_set_camera_f64", "rtow_render", "rtow_render_async", "rtow_sync",
-           "rtow_render_multi", "rtow_multi_plan", "rtow_interval_plan", "rtow_trace_rays", "rtow_get_rays", "rtow_scatter_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
+           "rtow_render_multi", "rtow_multi_plan", "rtow_interval_plan", "rtow_mask_plan", "rtow_trace_rays", "rtow_get_rays", "rtow_scatter_rays", "rtow_render_pass", "rtow_render_noalloc", "rtow_read_image", "rtow_format_ppm", "rtow_selftest_arithmetic", "rtow_get_stats", "rtow_get_stream"]
 
 _lib = None
 
@@ -121,6 +121,8 @@ def load(path, strict=True):
     L.rtow_multi_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(C.c_uint64)]
     if hasattr(L, "rtow_interval_plan"):
         L.rtow_interval_plan.argtypes = [C.POINTER(CameraStruct64), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+    if hasattr(L, "rtow_mask_plan"):
+        L.rtow_mask_plan.argtypes = [C.POINTER(CameraStruct64), C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.rtow_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     L.rtow_set_camera_f64.argtypes = [vp, C.POINTER(CameraStruct64)]
     L.rtow_render.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp, vp, vp]

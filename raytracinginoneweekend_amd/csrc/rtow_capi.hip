@@ -143,6 +143,13 @@ const char* rccl_load() {
 }
 }  // namespace
 
+// Grid of image tiles of the mask test (rtow_kernels.hip, scan_masked): a ray with image coordinates (s, t) aims at
+// column trunc(med3(s * ks + cs, 0, smax)) and row trunc(med3(t * kt + ct, 0, tmax)).
+struct TilePlan {
+  float ks = 0.0f, cs = 0.0f, kt = 0.0f, ct = 0.0f, smax = 0.0f, tmax = 0.0f;
+  uint32_t ns = 1;   // columns; rows = tmax + 1; columns * rows <= 32
+};
+
 struct rtow_ctx {
   int device = 0;
   int n_cu = 0;
@@ -163,6 +170,10 @@ struct rtow_ctx {
   std::vector<uint8_t> host_regular;          // per list entry: 1 = in the binary32 table (|radius| < kBigRadius)
   std::vector<float> host_span_mid, host_span_half;   // staging of the uploads (must outlive the copies); s ranges, then t ranges
   bool spans_valid = false;                   // the tables match the current scene and camera, and the camera is a regular one
+  // mask test of the camera rays (build_tile_masks): derived from the same ranges
+  DevBuf tile_mask;
+  std::vector<uint32_t> host_tile_mask;       // staging of the upload
+  TilePlan tiles;
   int screen_launched = 0;                    // RTOW_SCREEN_* of the frame in flight
   rtow::CameraParams64 cam;
 
@@ -278,7 +289,7 @@ int rtow_destroy(rtow_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release_scratch(c);
-  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom_slab.release(); c->span_mid.release(); c->span_half.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
+  c->geom.release(); c->geom_rr.release(); c->geom_nk.release(); c->geom_slab.release(); c->span_mid.release(); c->span_half.release(); c->tile_mask.release(); c->geom64.release(); c->big.release(); c->shade.release(); c->rows.release(); c->accum.release();
   c->hit_id.release(); c->rgb.release(); c->counters.release();
   c->ppm_len.release(); c->ppm_off.release(); c->ppm_text.release(); c->ray_in.release(); c->ray_out.release(); c->gather.release();
   if (c->gather_host) (void)hipHostFree(c->gather_host);
@@ -376,6 +387,94 @@ static void span_of_sphere(const rtow::CameraParams64& cam, const SpanCamera& sc
   half = std::nextafter((float)(std::max(s_hi - (double)m, (double)m - s_lo) + pad), INFINITY);
 }
 
+// Column (or row) of the tile a coordinate falls into: the kernel's tile_bit, operation for operation (one fused
+// multiply-add in binary32, v_med3_f32 - which returns the smallest operand when one is NaN, here 0 - and a truncation).
+// Monotonic in v for k >= 0, which is all the mask test needs from it.
+static uint32_t tile_index(float v, float k, float c, float vmax) {
+  const float x = std::fmaf(v, k, c);
+  if (!(x > 0.0f)) return 0u;
+  return (uint32_t)(x > vmax ? vmax : x);
+}
+
+// Mask test of the camera rays: per group of four spheres the tiles of the image its spheres' ranges (mid -+ half per
+// list entry and axis; half < 0 = no camera ray can meet the sphere) reach into.  A ray that can meet a sphere has its
+// binary32 s between the sphere's range ends rounded outwards, so - tile_index being monotonic - its column lies
+// between the columns of those two values; the same for t and rows.  Image coordinates run from 0 to
+// 1 + 1 / (kTileFrameMin - 1) for the frames the test is used on: a sphere whose range ends below 0 or starts beyond
+// that on either axis gets no tile.  The grid covers the part of the image the other spheres' ranges span (what lies
+// outside falls into the edge tiles, on both sides of the comparison), with the split into columns and rows that lets
+// the fewest (tile, group) pairs through, weighted by tile area.
+static void build_tile_masks(int n, const float* mid_s, const float* half_s, const float* mid_t, const float* half_t,
+                             TilePlan& plan, std::vector<uint32_t>& masks) {
+  const double top = 1.0 + 1.0 / (rtow::kTileFrameMin - 1);
+  struct Box { float lo[2], hi[2]; };
+  std::vector<Box> boxes((size_t)n);
+  std::vector<uint8_t> used((size_t)n, 0);
+  double h0[2] = {INFINITY, INFINITY}, h1[2] = {-INFINITY, -INFINITY};
+  for (int j = 0; j < n; ++j) {
+    const float mid[2] = {mid_s[j], mid_t[j]}, half[2] = {half_s[j], half_t[j]};
+    bool in = true;
+    Box b;
+    for (int a = 0; a < 2 && in; ++a) {
+      if (!(half[a] >= 0.0f)) { in = false; break; }
+      const double lo = (double)mid[a] - (double)half[a], hi = (double)mid[a] + (double)half[a];
+      if (hi < 0.0 || lo > top) { in = false; break; }
+      b.lo[a] = (float)lo; if ((double)b.lo[a] > lo) b.lo[a] = std::nextafter(b.lo[a], -INFINITY);
+      b.hi[a] = (float)hi; if ((double)b.hi[a] < hi) b.hi[a] = std::nextafter(b.hi[a], INFINITY);
+    }
+    if (!in) continue;
+    used[(size_t)j] = 1;
+    boxes[(size_t)j] = b;
+    for (int a = 0; a < 2; ++a) {
+      if (std::isfinite(b.lo[a])) h0[a] = std::min(h0[a], (double)b.lo[a]);
+      if (std::isfinite(b.hi[a])) h1[a] = std::max(h1[a], (double)b.hi[a]);
+    }
+  }
+  for (int a = 0; a < 2; ++a) {
+    h0[a] = std::max(h0[a], 0.0); h1[a] = std::min(h1[a], 1.0);
+    if (!(h1[a] - h0[a] > 1e-6)) { h0[a] = 0.0; h1[a] = 1.0; }
+  }
+  const size_t n_groups = ((size_t)n + 3) / 4;
+  if (masks.size() < n_groups) masks.resize(n_groups);
+  double best_cost = INFINITY;
+  std::vector<uint32_t> trial(masks.size());
+  for (uint32_t ns = 32; ns >= 1; ns /= 2) {
+    const uint32_t nt = 32 / ns;
+    TilePlan t;
+    t.ns = ns; t.smax = (float)(ns - 1); t.tmax = (float)(nt - 1);
+    t.ks = (float)(ns / (h1[0] - h0[0])); t.cs = (float)(-h0[0] * (double)t.ks);
+    t.kt = (float)(nt / (h1[1] - h0[1])); t.ct = (float)(-h0[1] * (double)t.kt);
+    std::fill(trial.begin(), trial.end(), 0u);
+    for (int j = 0; j < n; ++j) {
+      if (!used[(size_t)j]) continue;
+      const Box& b = boxes[(size_t)j];
+      const uint32_t c0 = tile_index(b.lo[0], t.ks, t.cs, t.smax), c1 = tile_index(b.hi[0], t.ks, t.cs, t.smax);
+      const uint32_t r0 = tile_index(b.lo[1], t.kt, t.ct, t.tmax), r1 = tile_index(b.hi[1], t.kt, t.ct, t.tmax);
+      uint32_t m = 0;
+      for (uint32_t r = r0; r <= r1; ++r)
+        for (uint32_t cc = c0; cc <= c1; ++cc) m |= 1u << (cc + ns * r);
+      trial[(size_t)j / 4] |= m;
+    }
+    // share of the image each column / row covers (the edge ones take what lies outside the grid)
+    double wide[32], high[32];
+    for (uint32_t i = 0; i < ns; ++i) {
+      const double a = i == 0 ? 0.0 : h0[0] + i * (h1[0] - h0[0]) / ns, b = i == ns - 1 ? 1.0 : h0[0] + (i + 1) * (h1[0] - h0[0]) / ns;
+      wide[i] = std::max(0.0, b - a);
+    }
+    for (uint32_t i = 0; i < nt; ++i) {
+      const double a = i == 0 ? 0.0 : h0[1] + i * (h1[1] - h0[1]) / nt, b = i == nt - 1 ? 1.0 : h0[1] + (i + 1) * (h1[1] - h0[1]) / nt;
+      high[i] = std::max(0.0, b - a);
+    }
+    double cost = 0.0;
+    for (size_t g = 0; g < n_groups; ++g)
+      for (uint32_t m = trial[g]; m != 0; m &= m - 1) {
+        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+        cost += wide[bit % ns] * high[bit / ns];
+      }
+    if (cost < best_cost) { best_cost = cost; plan = t; masks = trial; }
+  }
+}
+
 static int refresh_spans(rtow_ctx* c) {
   c->spans_valid = false;
   if (!c->have_scene || !c->have_camera) return RTOW_OK;
@@ -386,6 +485,7 @@ static int refresh_spans(rtow_ctx* c) {
   // per list entry the middle, per group of four the largest half width; the ranges of s, then those of t
   c->host_span_mid.assign((size_t)n_alloc * 2, kSpanNever);
   c->host_span_half.assign((size_t)(n_alloc / 4) * 2, -1.0f);
+  std::vector<float> own_half((size_t)n * 2, -1.0f);   // per list entry: its own half widths (s, then t), for the masks
   for (int axis = 0; axis < 2; ++axis) {
     float* const mids = c->host_span_mid.data() + (size_t)axis * (size_t)n_alloc;
     float* const halves = c->host_span_half.data() + (size_t)axis * (size_t)(n_alloc / 4);
@@ -394,13 +494,18 @@ static int refresh_spans(rtow_ctx* c) {
       float mid, half;
       span_of_sphere(c->cam, sc, axis, c->host_geom64[(size_t)j], mid, half);
       mids[(size_t)j] = mid;
+      own_half[(size_t)axis * (size_t)n + (size_t)j] = half;
       if (half > halves[(size_t)(j / 4)]) halves[(size_t)(j / 4)] = half;
     }
   }
+  c->host_tile_mask.assign(((size_t)(c->n_geom_pad / 4) + 15) / 16 * 16 + rtow::kTileMaskPad, 0u);
+  build_tile_masks(n, c->host_span_mid.data(), own_half.data(), c->host_span_mid.data() + n_alloc, own_half.data() + n,
+                   c->tiles, c->host_tile_mask);
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));   // a render may still be reading the old tables
   HIP_TRY(hipMemcpyAsync(c->span_mid.p, c->host_span_mid.data(), sizeof(float) * c->host_span_mid.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->span_half.p, c->host_span_half.data(), sizeof(float) * c->host_span_half.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->tile_mask.p, c->host_tile_mask.data(), sizeof(uint32_t) * c->host_tile_mask.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->spans_valid = true;
   return RTOW_OK;
@@ -430,6 +535,30 @@ int rtow_interval_plan(const rtow_camera_f64* cam, int n, const double* cx, cons
       if (m) m[j] = mid;
       if (h) h[j] = half;
     }
+  return RTOW_OK;
+}
+
+int rtow_mask_plan(const rtow_camera_f64* cam, int n, const double* cx, const double* cy, const double* cz,
+                   const double* radius, uint32_t* group_mask, float* grid, int* columns, int* covered) {
+  if (!cam || n < 0 || (n > 0 && (!cx || !cy || !cz || !radius)))
+    return fail(RTOW_ERR_INVALID, "rtow_mask_plan: NULL argument or n = %d", n);
+  try {
+    std::vector<float> spans((size_t)n * 4, 0.0f);
+    float* const ms = spans.data(); float* const hs = ms + n; float* const mt = hs + n; float* const ht = mt + n;
+    int cov = 0;
+    const int rc = rtow_interval_plan(cam, n, cx, cy, cz, radius, ms, hs, mt, ht, &cov);
+    if (rc != RTOW_OK) return rc;
+    if (covered) *covered = cov;
+    if (!cov) return RTOW_OK;
+    TilePlan plan;
+    std::vector<uint32_t> masks(((size_t)n + 3) / 4, 0u);
+    build_tile_masks(n, ms, hs, mt, ht, plan, masks);
+    if (group_mask) std::copy(masks.begin(), masks.begin() + ((size_t)n + 3) / 4, group_mask);
+    if (grid) { grid[0] = plan.ks; grid[1] = plan.cs; grid[2] = plan.kt; grid[3] = plan.ct; grid[4] = plan.smax; grid[5] = plan.tmax; }
+    if (columns) *columns = (int)plan.ns;
+  } catch (const std::exception& e) {
+    return fail(RTOW_ERR_NOMEM, "rtow_mask_plan: %s", e.what());
+  }
   return RTOW_OK;
 }
 
@@ -586,6 +715,7 @@ static int set_scene_impl(rtow_ctx* c, int n, const T* cx, const T* cy, const T*
   HIP_TRY(c->geom_nk.reserve(sizeof(float) * nk.size()));
   HIP_TRY(c->span_mid.reserve(sizeof(float) * (size_t)(n_pad + 4 * rtow::kSpanPadGroups) * 2));        // filled by refresh_spans once a camera is known
   HIP_TRY(c->span_half.reserve(sizeof(float) * (size_t)(n_pad / 4 + rtow::kSpanPadGroups) * 2));
+  HIP_TRY(c->tile_mask.reserve(sizeof(uint32_t) * (((size_t)(n_pad / 4) + 15) / 16 * 16 + rtow::kTileMaskPad)));
   HIP_TRY(c->geom_slab.reserve(sizeof(float) * slab.size()));
   HIP_TRY(hipMemcpyAsync(c->geom_slab.p, slab.data(), sizeof(float) * slab.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c->shade.reserve(sizeof(rtow::SphereShade) * shade.size()));
@@ -687,6 +817,9 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   p.geom64 = (const double4*)c->geom64.p; p.n_list = c->n_spheres;
   p.geom_slab = (const float*)c->geom_slab.p;
   p.span_mid = (const float*)c->span_mid.p; p.span_half = (const float*)c->span_half.p;
+  p.tile_mask = (const uint32_t*)c->tile_mask.p;
+  p.tile_ks = c->tiles.ks; p.tile_cs = c->tiles.cs; p.tile_kt = c->tiles.kt; p.tile_ct = c->tiles.ct;
+  p.tile_smax = c->tiles.smax; p.tile_tmax = c->tiles.tmax; p.tile_ns = c->tiles.ns;
   p.cmax = c->cmax;
   p.slab_inv_rmin = c->slab_inv_rmin;
   p.pad_ = 0.0f;
@@ -731,23 +864,29 @@ static int launch_frame(rtow_ctx* c, int w, int h, int spp, int max_depth, uint6
   HIP_TRY(hipMemsetAsync(t.counters, 0, kCounterBytes, c->stream));
   if (first_sample == 0 && n_pixels) HIP_TRY(hipMemsetAsync(t.accum, 0, sizeof(unsigned long long) * 3 * n_pixels, c->stream));
   HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-  // What the camera rays of a wave see before the filter (rtow_kernels.hip): by default the interval test
-  // (scan_interval: the ray's image coordinate against the range in which the sphere can be met; tables from
-  // refresh_spans), or, for a camera that construction does not cover, the slab test along the axis the view direction
-  // is most perpendicular to (pair_slab).  In both every ray still tests every sphere itself.  The image does not
-  // depend on the choice; for measurements and tests: RTOW_NO_SLAB_TEST = nothing in front of the filter,
-  // RTOW_CAMERA_SCREEN=slab = the slab test, RTOW_SLAB_AXIS=0|1|2 = the slab test along a given axis,
+  // What the camera rays of a wave see before the filter (rtow_kernels.hip): by default the mask test followed by the
+  // interval test (scan_masked: the tile of the image the ray aims at against the tiles in which a group's spheres can
+  // be met, then scan_interval's test - the ray's image coordinates against the ranges in which the sphere can be met -
+  // on the groups that pass; tables from refresh_spans); the interval test alone for frames under kTileFrameMin pixels
+  // wide or high; or, for a camera that construction does not cover, the slab test along the axis the view direction
+  // is most perpendicular to (pair_slab).  In all of them every ray still tests every group of the list itself.  The
+  // image does not depend on the choice; for measurements and tests: RTOW_NO_SLAB_TEST = nothing in front of the filter,
+  // RTOW_CAMERA_SCREEN=interval = the interval test without the masks, RTOW_CAMERA_SCREEN=slab = the slab test,
+  // RTOW_SLAB_AXIS=0|1|2 = the slab test along a given axis,
   // RTOW_CAMERA_SCREEN=bundle = the bundle test (scan_bundle: the table against the wave's 64 rays as a whole).  The
   // bundle test decides about a sphere once per wave instead of once per ray, which is culling by ray packets rather
   // than brute force: it is an option, never the default.
-  int slab_axis = c->spans_valid ? rtow::kIntervalTest : c->slab_axis;
+  const bool masks_apply = w >= rtow::kTileFrameMin && h >= rtow::kTileFrameMin;   // what build_tile_masks assumed of s and t
+  int slab_axis = c->spans_valid ? (masks_apply ? rtow::kMaskTest : rtow::kIntervalTest) : c->slab_axis;
   if (getenv("RTOW_NO_SLAB_TEST")) slab_axis = -1;
   else if (const char* e = getenv("RTOW_SLAB_AXIS")) { const int v = atoi(e); if (v >= 0 && v <= 2) slab_axis = v; }
   else if (const char* s = getenv("RTOW_CAMERA_SCREEN")) {
     if (!strcmp(s, "bundle")) slab_axis = rtow::kBundleTest;
     else if (!strcmp(s, "slab")) slab_axis = c->slab_axis;
+    else if (!strcmp(s, "interval") && c->spans_valid) slab_axis = rtow::kIntervalTest;
   }
-  c->screen_launched = slab_axis < 0 ? RTOW_SCREEN_NONE : slab_axis == rtow::kIntervalTest ? RTOW_SCREEN_INTERVAL
+  c->screen_launched = slab_axis < 0 ? RTOW_SCREEN_NONE : slab_axis == rtow::kMaskTest ? RTOW_SCREEN_MASK
+                     : slab_axis == rtow::kIntervalTest ? RTOW_SCREEN_INTERVAL
                      : slab_axis == rtow::kBundleTest ? RTOW_SCREEN_BUNDLE : RTOW_SCREEN_SLAB;
   if (n_pixels) rtow::launch_trace(p, slab_axis, grid, c->stream);
   HIP_TRY(hipGetLastError());

@@ -27,6 +27,12 @@ struct TraceParams {
                              // in which a camera ray can meet the sphere (n_geom_pad + 4 kSpanPadGroups values), then the same for t ...
   const float* span_half;    // ... and per group of four the largest half width of its four ranges (negative: never passes;
                              // n_geom_pad / 4 + kSpanPadGroups values for s, then as many for t)
+  const uint32_t* tile_mask; // mask test of the camera rays: per group of four one bit per tile of the image in which a camera ray can
+                             // meet one of its spheres (n_geom_pad / 4 rounded up to a multiple of 16, + kTileMaskPad values)
+  float tile_ks, tile_cs;    // column of the tile a ray with image coordinate s aims at: trunc(med3(s * tile_ks + tile_cs, 0, tile_smax))
+  float tile_kt, tile_ct;    // its row, from t, likewise
+  float tile_smax, tile_tmax;// columns - 1, rows - 1 (columns * rows <= 32)
+  uint32_t tile_ns;          // columns: the tile's bit is column + tile_ns * row
   int n_geom_pad;
   int n_list;                // spheres in the list (= entries of geom64 and shade)
   float cmax;                // max(|c| + |r|) over the regular spheres: scales the filter margin
@@ -91,9 +97,13 @@ struct ScatterParams {
 void launch_scatter(const ScatterParams& p, hipStream_t stream);
 
 // slab_axis: what the camera rays see before the filter: the slab test along axis 0, 1 or 2 (see pair_slab), the
-// bundle test (kBundleTest; see scan_bundle), the interval test (kIntervalTest; see scan_interval), or -1 for nothing
+// bundle test (kBundleTest; see scan_bundle), the interval test (kIntervalTest; see scan_interval), the mask test in front of
+// the interval test (kMaskTest; see scan_masked), or -1 for nothing
 constexpr int kBundleTest = 3;
 constexpr int kIntervalTest = 4;
+constexpr int kMaskTest = 5;
+constexpr int kTileMaskPad = 32;    // all-zero masks behind the last block of 16 groups (the mask test's loop requests ahead)
+constexpr int kTileFrameMin = 16;   // the masks are made for frames at least this wide and high (s, t <= 1 + 1 / (kTileFrameMin - 1))
 constexpr int kSpanPadGroups = 4;   // all-padding groups behind the last one in the interval test's tables (its loop requests two pairs ahead)
 void launch_trace(const TraceParams& p, int slab_axis, int grid_blocks, hipStream_t stream);
 void launch_resolve(const unsigned long long* accum, uint8_t* rgb, uint32_t n_channels, int spp,

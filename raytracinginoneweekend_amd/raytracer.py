@@ -242,6 +242,37 @@ def intervalPlan(camera, world, lib=None):
     return tuple(out) if covered.value else None
 
 
+def maskPlan(camera, world, lib=None):
+    """rtow_mask_plan: the tile grid and, per group of four spheres of `world`, the word of tiles in which a camera ray can
+    meet one of them, as (group_mask uint32 [(n + 3) // 4], grid float32 [6], columns), or None when the camera is not
+    one the construction covers.  tileOf(grid, columns, s, t) gives the bit of a ray.  Plain host arithmetic: needs no GPU."""
+    L = lib or _lib.lib()
+    flat = world.flatten() if hasattr(world, "flatten") else world
+    cx, cy, cz, rad = (np.ascontiguousarray(flat[k], np.float64) for k in ("center_x", "center_y", "center_z", "radius"))
+    n = len(rad)
+    masks = np.zeros((n + 3) // 4, np.uint32)
+    grid = np.zeros(6, np.float32)
+    columns, covered = C.c_int(0), C.c_int(0)
+    cam = camera.to_struct() if isinstance(camera, Camera) else camera
+    _lib.check(L.rtow_mask_plan(C.byref(cam), n, cx.ctypes.data, cy.ctypes.data, cz.ctypes.data, rad.ctypes.data,
+                                masks.ctypes.data, grid.ctypes.data, C.byref(columns), C.byref(covered)))
+    return (masks, grid, columns.value) if covered.value else None
+
+
+def tileOf(grid, columns, s, t):
+    """Bit index of the image tile a ray with image coordinates (s, t) aims at (arrays allowed), in the renderer's own
+    binary32 arithmetic: one fused multiply-add, a clamp to [0, last], a truncation, per axis."""
+    def index(v, k, c, last):
+        v = np.asarray(v, np.float32)
+        # a binary32 fused multiply-add: the product of two binary32 values is exact in binary64, and so is the sum here
+        # up to one rounding, which differs from the fused one only in double-rounding cases the comparison below absorbs
+        x = (v.astype(np.float64) * np.float64(k) + np.float64(c))
+        x32 = x.astype(np.float32)
+        x32 = np.where(x32 > 0, np.minimum(x32, np.float32(last)), np.float32(0))
+        return x32.astype(np.int64)
+    return index(s, grid[0], grid[1], grid[4]) + columns * index(t, grid[2], grid[3], grid[5])
+
+
 def multiPlan(width, height, n_ctx, tile=4, lib=None):
     """The dealing of rows behind renderMulti (rtow_multi_plan; no GPU is touched): returns
     (ctx_of_row int32 [height], index_in_ctx int32 [height], rows_per_ctx int32 [n_ctx], slot_bytes)."""

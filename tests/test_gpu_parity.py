@@ -692,11 +692,13 @@ def test_table_sizes_around_the_lds_thresholds(oracle):
 
 
 def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
-    """Camera rays see a cheap necessary condition per (ray, sphere) pair before the 7-FMA screen: by default the
-    interval test (the ray's image coordinate against the range in which the sphere can be met at all), for other
-    cameras and on request (RTOW_CAMERA_SCREEN=slab) the slab test along the axis the host picks from the camera.
-    Either may only drop spheres the ray misses: with the default, without any such test (RTOW_NO_SLAB_TEST, read at
-    every launch), with the slab test along each of the three axes (RTOW_SLAB_AXIS) and with the optional bundle test
+    """Camera rays see cheap necessary conditions before the 7-FMA screen: by default the mask test (the image tile
+    the ray aims at against the tiles in which a group's spheres can be met) and then the interval test (the ray's
+    image coordinates against the ranges in which the sphere can be met at all; alone with
+    RTOW_CAMERA_SCREEN=interval), for other cameras and on request (RTOW_CAMERA_SCREEN=slab) the slab test along the
+    axis the host picks from the camera.  Each may only drop spheres the ray misses: with the default, without any
+    such test (RTOW_NO_SLAB_TEST, read at every launch), with the interval test alone, with the slab test along each
+    of the three axes (RTOW_SLAB_AXIS) and with the optional bundle test
     hit ids, sums and segment counts are the same - on the book scene, with
     the camera looking straight down and straight up (a projection degenerates), from inside a glass sphere, on a
     vertical stack of spheres, on a table beyond the LDS sizes - and equal the mirror, which has no such test."""
@@ -724,8 +726,8 @@ def test_slab_test_of_camera_rays_changes_nothing(oracle, monkeypatch):
             r.setCamera(initCamera(point(*cam["look_from"]), point(*cam["look_at"]), vec3(0, 1, 0), vfov=cam["vfov"],
                                    aspectRatio=W / H, aperture=cam["aperture"], focusDist=cam["focus"]))
             ref = oracle.render_mirror32(arr, n, oracle.book_camera(W / H, **cam), W, H, spp, depth, threads=16)
-            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}, {"RTOW_CAMERA_SCREEN": "slab"}, {"RTOW_SLAB_AXIS": "0"}, {"RTOW_SLAB_AXIS": "1"},
-                        {"RTOW_SLAB_AXIS": "2"}, {"RTOW_CAMERA_SCREEN": "bundle"}):
+            for env in ({}, {"RTOW_NO_SLAB_TEST": "1"}, {"RTOW_CAMERA_SCREEN": "interval"}, {"RTOW_CAMERA_SCREEN": "slab"}, {"RTOW_SLAB_AXIS": "0"},
+                        {"RTOW_SLAB_AXIS": "1"}, {"RTOW_SLAB_AXIS": "2"}, {"RTOW_CAMERA_SCREEN": "bundle"}):
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
@@ -780,8 +782,8 @@ def test_camera_the_interval_test_does_not_cover_falls_back_to_the_slab_test(ora
 
 
 def test_interval_test_on_random_cameras_and_worlds(monkeypatch):
-    """The interval test's tables come from host code that sees scene and camera (ranges of the image coordinates per
-    sphere).  Forty seeded random look-at cameras - near, far and inside the field, looking up, down and along the
+    """The tables of the mask test and of the interval test come from host code that sees scene and camera (ranges of
+    the image coordinates per sphere, and the image tiles they reach into per group of four).  Forty seeded random look-at cameras - near, far and inside the field, looking up, down and along the
     ground, closed to very wide lenses, focus in front of and behind the spheres, rolled - on the book scene and on
     random worlds with overlapping spheres of either sign of radius: the image with the test must be the image
     without it (hit ids, 64-bit sums, pixels, segment count), and the stats must say which test ran."""
@@ -812,7 +814,7 @@ def test_interval_test_on_random_cameras_and_worlds(monkeypatch):
             spp = int(rng.choice([1, 7, 64, 130]))
             got = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
             st = r.stats()
-            assert st["camera_screen"] == _lib.SCREEN_INTERVAL, case
+            assert st["camera_screen"] == _lib.SCREEN_MASK, case
             monkeypatch.setenv("RTOW_NO_SLAB_TEST", "1")
             plain = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
             monkeypatch.delenv("RTOW_NO_SLAB_TEST")
@@ -820,11 +822,26 @@ def test_interval_test_on_random_cameras_and_worlds(monkeypatch):
             assert (got[2] == plain[2]).all(), (case, int((got[2] != plain[2]).sum()))
             assert (got[1] == plain[1]).all() and (got[0] == plain[0]).all(), case
             assert st["ray_segments"] == r.stats()["ray_segments"], case
+            monkeypatch.setenv("RTOW_CAMERA_SCREEN", "interval")   # the interval test without the masks in front of it
+            alone = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
+            monkeypatch.delenv("RTOW_CAMERA_SCREEN")
+            assert r.stats()["camera_screen"] == _lib.SCREEN_INTERVAL
+            assert (alone[2] == plain[2]).all() and (alone[1] == plain[1]).all() and (alone[0] == plain[0]).all(), case
+            assert st["ray_segments"] == r.stats()["ray_segments"], case
             if case % 10 == 0:   # the same camera set again keeps the tables; a changed world rebuilds them
                 r.setCamera(cam)
                 again = r.renderRows(W, H, spp, depth, want_accum=True, want_hit_id=True)
-                assert r.stats()["camera_screen"] == _lib.SCREEN_INTERVAL
+                assert r.stats()["camera_screen"] == _lib.SCREEN_MASK
                 assert (again[1] == got[1]).all() and (again[2] == got[2]).all()
+            if case % 5 == 0:    # frames under 16 pixels wide or high (image coordinates beyond what the masks were made for,
+                                 # up to 2 for two rows or columns): the interval test alone
+                for w2, h2 in ((9, 48), (72, 7), (2, 20), (33, 2), (15, 15), (16, 16)):
+                    small = r.renderRows(w2, h2, 3, depth, want_accum=True, want_hit_id=True)
+                    assert r.stats()["camera_screen"] == (_lib.SCREEN_MASK if min(w2, h2) >= 16 else _lib.SCREEN_INTERVAL), (w2, h2)
+                    monkeypatch.setenv("RTOW_NO_SLAB_TEST", "1")
+                    small_plain = r.renderRows(w2, h2, 3, depth, want_accum=True, want_hit_id=True)
+                    monkeypatch.delenv("RTOW_NO_SLAB_TEST")
+                    assert (small[2] == small_plain[2]).all() and (small[1] == small_plain[1]).all(), (case, w2, h2)
 
 
 def test_optional_bundle_test_of_camera_rays_changes_nothing(oracle, monkeypatch):

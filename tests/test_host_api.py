@@ -288,7 +288,7 @@ def test_interval_plan_of_the_library_is_conservative():
     from raytracinginoneweekend_amd.camera import initCamera
     rng = np.random.default_rng(5)
     f32 = np.float32
-    checked = 0
+    checked = mask_checked = mask_bits = mask_words = 0
     for trial in range(30):
         spread = float(rng.choice([3.0, 11.0, 60.0]))
         n = 200
@@ -328,7 +328,20 @@ def test_interval_plan_of_the_library_is_conservative():
                 passes = np.abs(mid[None, :] - coord.astype(f32)[:, None]) <= half[None, :]
             assert passes[forward].all(), (trial, int((~passes[forward]).sum()))
         checked += int(forward.sum())
-    assert checked > 10000
+        # rtow_mask_plan, the words in front of that comparison: a ray that meets a sphere aims at a tile whose bit is set
+        # in the word of the sphere's group of four (for the image coordinates a frame has: s, t >= 0)
+        masks, grid, columns = R.maskPlan(cam, world)
+        assert columns in (1, 2, 4, 8, 16, 32) and grid[4] == columns - 1 and grid[5] == 32 // columns - 1
+        bit = R.tileOf(grid, columns, s, t)
+        assert ((0 <= bit) & (bit < 32)).all()
+        word = masks[(np.arange(1, n) // 4)]
+        has_bit = ((word[None, :] >> bit[:, None].astype(np.uint32)) & 1).astype(bool)
+        in_frame = ((s >= 0) & (t >= 0))[:, None]
+        assert has_bit[forward & in_frame].all(), (trial, int((~has_bit[forward & in_frame]).sum()))
+        mask_checked += int((forward & in_frame).sum())
+        mask_bits += int(np.unpackbits(masks.view(np.uint8)).sum()); mask_words += len(masks)
+    assert checked > 10000 and mask_checked > 10000
+    assert mask_bits < 0.5 * 32 * mask_words      # and the words are selective: under half of all (tile, group) pairs on average
     # cameras the construction does not cover
     book = R.bookCamera(1.5)
     sheared = book.to_struct()
