@@ -19,9 +19,9 @@ Prints ONE JSON line on rank 0.  value = ray segments (world.hit queries) of all
 seconds / 1e6.  roofline: algorithmic FLOP (18 per ray-sphere test, 18*N+65 per segment) over
 the trace kernel's own duration, measured with HIP events on the stream it runs on in three
 un-overlapped steps after the timed region (the median of the three).  The same three steps
-are then repeated with the camera rays' first test switched off (frac_without_first_test),
-with the slab test in its place, and with the optional bundle test; none of those enters
-`value` or `frac`.
+are then repeated with the camera rays' first tests switched off (frac_without_first_test),
+with the interval test alone, with the slab test in their place, and with the optional bundle
+test; none of those enters `value` or `frac`.
 cpu_baseline: the FP64 CPU restatement of the reference (oracle/, "port") timed on this box's
 host cores on a bounded sample of the same frame.
 """
@@ -40,8 +40,10 @@ FLOP_PER_SEGMENT_EXTRA = 65    # a = |dir|^2 once, hit epilogue, scatter, sky (a
 FLOP_PER_TEST_EXECUTED = 14    # what the kernel's screen really issues per sphere: 7 packed FMAs per pair
 # camera rays (one pixel's samples per wave) see a cheaper necessary condition per (ray, sphere) pair first, and only the
 # groups of four spheres that pass it in some lane go on to the screen (screen_pass_fraction() below):
-FLOP_PER_CAMERA_TEST = {"interval": 1, "slab": 4, "none": 0}   # one subtraction; two FMAs; nothing
-SCREEN_NAMES = {0: "none", 1: "slab", 2: "interval", 3: "bundle"}   # rtow_stats.camera_screen
+# one subtraction; two FMAs; nothing; one AND per group of four spheres (plus two subtractions for the pairs of the groups
+# whose word has the ray's bit: mask_word_pass in the same file)
+FLOP_PER_CAMERA_TEST = {"interval": 1, "slab": 4, "none": 0, "mask": 0.25}
+SCREEN_NAMES = {0: "none", 1: "slab", 2: "interval", 3: "bundle", 4: "mask"}   # rtow_stats.camera_screen
 
 WORKLOADS = {
     # name: (width, height, spp, depth, half_extent, lambert_below, metal_below)
@@ -59,7 +61,10 @@ def screen_pass_fraction(workload, spp, screen):
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_screen_pass_fraction.json")))
     if not found or spp != WORKLOADS[workload][2]:
         return None
-    return json.load(open(found[-1])).get(screen, {}).get(workload)
+    table = json.load(open(found[-1]))
+    if screen == "mask_word_pass":
+        return table.get(screen, {}).get(workload, 0.0)
+    return table.get(screen, {}).get(workload)
 
 
 def hbm_traffic(workload, spp, world):
@@ -338,9 +343,11 @@ def main():
         assert steps[-1]["ray_segments"] == serial[-1]["ray_segments"]
         return sorted(st["trace_ms"] for st in steps)[mid]
 
-    bundle_ms = slab_ms = None
+    bundle_ms = slab_ms = interval_ms = None
     if slab_used and "RTOW_SLAB_AXIS" not in os.environ and "RTOW_CAMERA_SCREEN" not in os.environ:
-        if screen == "interval":
+        if screen == "mask":
+            interval_ms = variant("interval")
+        if screen in ("mask", "interval"):
             slab_ms = variant("slab")
         bundle_ms = variant("bundle")
 
@@ -360,8 +367,9 @@ def main():
         if pass_fraction is None or screen not in FLOP_PER_CAMERA_TEST:
             executed = None
         else:
+            first = FLOP_PER_CAMERA_TEST[screen] + (2 * screen_pass_fraction(args.workload, spp, "mask_word_pass") if screen == "mask" else 0)
             executed = ((serial[-1]["ray_segments"] - (serial[-1]["paths"] if slab_used else 0)) * FLOP_PER_TEST_EXECUTED
-                        + (serial[-1]["paths"] * (FLOP_PER_CAMERA_TEST[screen] + pass_fraction * FLOP_PER_TEST_EXECUTED) if slab_used else 0)
+                        + (serial[-1]["paths"] * (first + pass_fraction * FLOP_PER_TEST_EXECUTED) if slab_used else 0)
                         ) * n_spheres / avg_trace_s / 1e12 / PEAK_FP32_VALU_TFLOPS
         out = {
             "metric": "Mrays/sec (ray segments = world.hit queries) book-1 final scene 1200x800 spp500 depth50"
@@ -406,13 +414,14 @@ def main():
                 # `achieved` counts the reference's work (18 FLOP per ray-sphere test, hitrecord.nim:56-61); the
                 # kernel screens every sphere with 14 FLOP (7 packed FMAs per pair) and runs the full test on
                 # the ~1.2 survivors per ray, so the share of the VALU peak it really issues is lower:
-                # (camera-ray segments - one per path - see the first test, one subtraction per pair for the interval
-                # test, and the screen only for the groups that pass it)
+                # (camera-ray segments - one per path - see the first tests - one AND per group of four for the mask test,
+                # one subtraction per pair and axis for the interval test on the groups that pass it - and the screen only
+                # for the groups that pass both)
                 "frac_executed_screen_only": executed,
                 "camera_ray_first_test": screen,
                 "first_test_pass_fraction": pass_fraction if slab_used else None,
                 "note": "achieved = ray segments x the reference's 18 FLOP per ray-sphere pair (+65 per segment); the kernel decides "
-                        "most pairs with fewer operations (one subtraction for a camera ray's pair, 7 FMAs otherwise: "
+                        "most pairs with fewer operations (a quarter of an AND for a camera ray's pair, 7 FMAs otherwise: "
                         "frac_executed_screen_only), so frac measures work delivered against the VALU peak and can approach or "
                         "exceed 1; frac_without_first_test is the same frame with every pair going through the 7-FMA screen",
                 "kernel_ms_without_first_test": no_slab_ms,
@@ -420,6 +429,8 @@ def main():
                 # (the names these two figures had before the interval test replaced the slab test as the default)
                 "kernel_ms_without_slab_test": no_slab_ms,
                 "frac_without_slab_test": (serial[-1]["ray_segments"] * flop_per_segment / (no_slab_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if no_slab_ms else None,
+                "kernel_ms_with_interval_test_instead": interval_ms,
+                "frac_with_interval_test_instead": None if interval_ms is None else serial[-1]["ray_segments"] * flop_per_segment / (interval_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                 "kernel_ms_with_slab_test_instead": slab_ms,
                 "frac_with_slab_test_instead": None if slab_ms is None else serial[-1]["ray_segments"] * flop_per_segment / (slab_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                 # NOT the headline and not brute force: the same frame with RTOW_CAMERA_SCREEN=bundle, where each wave

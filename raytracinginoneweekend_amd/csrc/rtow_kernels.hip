@@ -923,7 +923,11 @@ template <bool K_LDS, bool SHORT, typename ExactPtr>
 static __device__ __forceinline__ void masked_block(const u4v m, const uint32_t bit, const f2v st, int g, int n_groups, geom_ptr geom,
                                                     nk_lds_ptr nk, ExactPtr exact, CandList<SHORT>& cand, const ScanRay& r, f3 o, f3 u,
                                                     const PrimaryCtx& pc RTOW_PROF_PARAM) {
-  const uint32_t any = (m.x & bit) | (m.y & bit) | (m.z & bit) | (m.w & bit);
+  // the ray's bit against the word of each of the four groups, the results ORed together: v_and_b32 and three
+  // v_and_or_b32 (spelled out: from (a & x) | (b & x) ... the compiler builds a longer sequence)
+  uint32_t any;
+  asm("v_and_b32 %0, %1, %5\n\tv_and_or_b32 %0, %2, %5, %0\n\tv_and_or_b32 %0, %3, %5, %0\n\tv_and_or_b32 %0, %4, %5, %0"
+      : "=&v"(any) : "s"(m.x), "s"(m.y), "s"(m.z), "s"(m.w), "v"(bit));
   if (__ballot(any != 0u) == 0) return;   // wave-uniform: no ray of the wave aims at a tile any of the sixteen reaches into
   if (__ballot((m.x & bit) != 0u) != 0) masked_group<K_LDS>(st, g, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);
   if (__ballot((m.y & bit) != 0u) != 0) masked_group<K_LDS>(st, g + 1, n_groups, geom, nk, exact, cand, r, o, u, pc RTOW_PROF_ARG);

@@ -32,4 +32,4 @@ print(f"BOUNCE shading: sky {b[16]/(64*bounce):.3f}, Lambertian {b[17]/(64*bounc
 if b[11]:
     print(f"unit-ball search: {b[11]/it:.2f} passes per iteration (both kinds), {b[20]/b[11]:.1f} lanes looking per pass")
 print(f"camera-ray screen: {b[24]/prim:.1f} groups of a PRIMARY scan go on to the filter (of {(len(scene)+7)//8*2}); "
-      f"{b[25]/prim:.1f} pass the interval test's first axis")
+      f"{b[25]/prim:.1f} pass the interval test's first axis" + (f"; {b[26]/prim:.1f} pass the mask test" if b[26] else ""))

@@ -1,11 +1,13 @@
 """What the cheap per-ray tests in front of the camera rays' screen are worth, and what that depends on.
 
-The default is the interval test (the ray's image coordinates against the ranges in which a sphere can be met at
-all); RTOW_CAMERA_SCREEN=slab selects the older slab test (distance to the ray's line seen along a world axis).
-Either lets a wave skip the 7-FMA screen for a group of four spheres when none of its 64 camera rays passes for
-any of them.  Those 64 rays are consecutive (pixel, sample) pairs of a chunk: 64 samples of ONE pixel when
+The default is the mask test (the image tile the ray aims at against the tiles in which a group's spheres can be met)
+followed by the interval test (the ray's image coordinates against the ranges in which a sphere can be met at all;
+alone with RTOW_CAMERA_SCREEN=interval); RTOW_CAMERA_SCREEN=slab selects the older slab test (distance to the ray's
+line seen along a world axis).  Each lets a wave skip the 7-FMA screen for a group of four spheres when none of its 64
+camera rays passes for any of them.  Those 64 rays are consecutive (pixel, sample) pairs of a chunk: 64 samples of ONE pixel when
 spp >= 64, several neighbouring pixels of a row when spp is smaller, and the lens spreads their origins over the
-aperture.  This script renders the same frame with the default test, with the slab test and with RTOW_NO_SLAB_TEST=1 (read at every launch)
+aperture.  This script renders the same frame with the default tests, with the interval test alone, with the slab test and with
+RTOW_NO_SLAB_TEST=1 (read at every launch)
 over sample counts, apertures, a camera inside the sphere field, the all metal / glass scene and the
 10 001-sphere scene, and reports trace-kernel times (HIP events, median of 3) and - from the instrumented
 build, when it is present - how many groups of a PRIMARY scan go on to the screen.
@@ -50,8 +52,8 @@ for spp in ((1, 8, 64) if not quick else (8,)):
 def timed(r, spp, mode):
     if mode == "none":
         os.environ["RTOW_NO_SLAB_TEST"] = "1"
-    elif mode == "slab":
-        os.environ["RTOW_CAMERA_SCREEN"] = "slab"
+    elif mode in ("slab", "interval"):
+        os.environ["RTOW_CAMERA_SCREEN"] = mode
     try:
         ms = []
         r.renderAsync(W, H, spp, DEPTH); r.sync()     # one untimed launch of this kernel instance first
@@ -78,9 +80,10 @@ for scene_name, cam_name, cam, spp in cases:
     r.setCamera(cam)
     t_with, seg = timed(r, spp, "default")
     t_slab, seg3 = timed(r, spp, "slab")
+    t_interval, seg4 = timed(r, spp, "interval")
     t_without, seg2 = timed(r, spp, "none")
-    assert seg == seg2 == seg3
-    rows.append([scene_name, cam_name, cam, spp, t_with, t_without, seg, "", t_slab])
+    assert seg == seg2 == seg3 == seg4
+    rows.append([scene_name, cam_name, cam, spp, t_with, t_without, seg, "", t_slab, t_interval])
     print(f"timed {scene_name} / {cam_name} / spp {spp}", file=sys.stderr, flush=True)
 r.close()
 if prof is not None:
@@ -101,11 +104,11 @@ if prof is not None:
         rp.renderAsync(W, H, min(spp, 64), DEPTH); rp.sync()
         prof.rtow_debug_counters(b, 0)
         groups = (n + 7) // 8 * 2
-        row[7] = f"{b[24] / max(1, b[14]):7.1f} of {groups} = {b[24] / max(1, b[14]) / groups:.3f}"
-print(f"{'scene':22s} {'camera':40s} {'spp':>4s} {'interval ms':>11s} {'slab ms':>9s} {'without ms':>10s} {'gain':>7s} {'slab gain':>9s} {'Mrays/s':>9s} {'frac':>6s} {'no-test frac':>12s} "
-      f"{'groups on to the screen':>24s}")
-for scene_name, cam_name, cam, spp, t_with, t_without, seg, passing, t_slab in rows:
+        row[7] = f"{b[26] / max(1, b[14]):6.1f} / {b[24] / max(1, b[14]):5.1f} of {groups} = {b[24] / max(1, b[14]) / groups:.3f}"
+print(f"{'scene':22s} {'camera':40s} {'spp':>4s} {'default ms':>11s} {'interval ms':>11s} {'slab ms':>9s} {'without ms':>10s} {'gain':>7s} {'intv gain':>9s} {'slab gain':>9s} {'Mrays/s':>9s} {'frac':>6s} {'no-test frac':>12s} "
+      f"{'groups past the masks / on to the screen':>40s}")
+for scene_name, cam_name, cam, spp, t_with, t_without, seg, passing, t_slab, t_interval in rows:
     n = len(scenes[scene_name])
     flop = seg * (18 * n + 65)
-    print(f"{scene_name:22s} {cam_name:40s} {spp:4d} {t_with:11.3f} {t_slab:9.3f} {t_without:10.3f} {100 * (t_without / t_with - 1):6.1f}% {100 * (t_without / t_slab - 1):8.1f}% "
-          f"{seg / t_with / 1e3:9.1f} {flop / t_with / 1e9 / 157.3:6.3f} {flop / t_without / 1e9 / 157.3:12.3f} {passing:>24s}", flush=True)
+    print(f"{scene_name:22s} {cam_name:40s} {spp:4d} {t_with:11.3f} {t_interval:11.3f} {t_slab:9.3f} {t_without:10.3f} {100 * (t_without / t_with - 1):6.1f}% {100 * (t_without / t_interval - 1):8.1f}% {100 * (t_without / t_slab - 1):8.1f}% "
+          f"{seg / t_with / 1e3:9.1f} {flop / t_with / 1e9 / 157.3:6.3f} {flop / t_without / 1e9 / 157.3:12.3f} {passing:>40s}", flush=True)

@@ -63,7 +63,7 @@ for k in sorted(pmc):
 # the last template argument of rtow_trace_kernel says what the camera rays see before the sphere screen
 labels = {"-1": "nothing in front of the screen (RTOW_NO_SLAB_TEST)", "0": "slab test along x", "1": "slab test along y",
           "2": "slab test along z", "3": "bundle test (RTOW_CAMERA_SCREEN=bundle: packet culling, not part of any quoted figure)",
-          "4": "interval test (the default)"}
+          "4": "interval test alone (RTOW_CAMERA_SCREEN=interval)", "5": "mask test, then interval test (the default)"}
 def label(name):
     import re
     m = re.search(r"rtow_trace_kernel<[^>]*,\s*(-?\d+)>", name)
