@@ -260,12 +260,13 @@ def maskPlan(camera, world, lib=None):
 
 
 def tileOf(grid, columns, s, t):
-    """Bit index of the image tile a ray with image coordinates (s, t) aims at (arrays allowed), in the renderer's own
-    binary32 arithmetic: one fused multiply-add, a clamp to [0, last], a truncation, per axis."""
+    """Bit index of the image tile a ray with image coordinates (s, t) aims at (arrays allowed), in the renderer's
+    binary32 arithmetic: one fused multiply-add, a clamp to [0, last], a truncation, per axis.  The fused
+    multiply-add is formed in binary64 and rounded to binary32 (the product of two binary32 values is exact there, the
+    sum is rounded twice), which can differ from the renderer's single rounding only for a coordinate within about
+    2^-29 of a tile edge: good for tests and tools, not a bit-for-bit statement."""
     def index(v, k, c, last):
         v = np.asarray(v, np.float32)
-        # a binary32 fused multiply-add: the product of two binary32 values is exact in binary64, and so is the sum here
-        # up to one rounding, which differs from the fused one only in double-rounding cases the comparison below absorbs
         x = (v.astype(np.float64) * np.float64(k) + np.float64(c))
         x32 = x.astype(np.float32)
         x32 = np.where(x32 > 0, np.minimum(x32, np.float32(last)), np.float32(0))
