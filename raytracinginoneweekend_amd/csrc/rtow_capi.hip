@@ -243,7 +243,7 @@ extern "C" {
 
 const char* rtow_last_error(void) { return g_err.c_str(); }
 
-int rtow_version(void) { return 10100; }   // 1.1.0: rtow_stats grew by camera_screen
+int rtow_version(void) { return 10200; }   // 1.1.0: rtow_stats grew by camera_screen; 1.2.0: rtow_mask_plan, RTOW_SCREEN_MASK
 
 int rtow_device_count(int* count) {
   if (!count) return fail(RTOW_ERR_INVALID, "rtow_device_count: count is NULL");

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rtow_version() == 10100
+    assert L.rtow_version() == 10200
     assert L.rtow_last_error() is not None
 
 
